@@ -1,0 +1,193 @@
+/* C ABI of the MI355X light transport library (libpt_hip.so).
+ *
+ * This is the boundary at which a C host shaped like the reference
+ * (MomentsInGraphics/path_tracer) hands its scene to the GPU: what the
+ * reference does with Vulkan buffers, an acceleration structure, a uniform
+ * block and one full-screen draw per frame, a caller does here with plain
+ * pointers and sizes. All functions return 0 on success and nonzero on
+ * failure after printing a message to stdout, like the reference's
+ * create_*() functions; none throws, exits or keeps host pointers beyond the
+ * call. The library is single-caller per scene handle; calls on one handle
+ * execute in call order.
+ *
+ * Citations name files of the reference relative to its root.
+ */
+#ifndef PT_HIP_H
+#define PT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The uniform block that the reference uploads once per frame:
+ * constants_t at src/main.h:237-256 = src/shaders/constants.glsl:1-39
+ * (784 bytes, std140, row_major matrices). frame_index and
+ * accum_frame_count are ignored here: pt_render_samples() takes the frame
+ * indices as arguments and the library counts accumulated frames itself. */
+typedef struct {
+	float world_to_projection_space[16];
+	float projection_to_world_space[16];
+	float camera_pos[3];
+	int32_t camera_type;
+	float hemispherical_camera_normal[3];
+	float pad_1;
+	float dequantization_factor[3], pad_2, dequantization_summand[3], pad_3;
+	float viewport_size[2], inv_viewport_size[2];
+	float exposure;
+	uint32_t frame_index;
+	uint32_t accum_frame_count;
+	float pad_4;
+	float sky_radiance[3];
+	float pad_5;
+	float emission_material_radiance[3];
+	float pad_6;
+	float params[4];
+	float spherical_lights[32][4];
+} pt_constants_t;
+
+/* Numbers from the .vks header, scene_file_header_t at src/scene.h:5-21 */
+typedef struct {
+	uint64_t material_count;
+	uint64_t triangle_count;
+	float dequantization_factor[3];
+	float dequantization_summand[3];
+} pt_scene_header_t;
+
+/* One texture as a .vkt file holds it (texture_header_t and mipmap_header_t
+ * at src/textures.c:8-33): raw block-compressed mip levels. format is the
+ * VkFormat number; 131 (BC1_RGB_UNORM), 132 (BC1_RGB_SRGB) and 141
+ * (BC5_UNORM) are supported. Extents must be powers of two, at least 4. */
+typedef struct {
+	uint32_t width, height;
+	uint32_t format;
+	uint32_t mip_count;
+	const void* const* mip_data;
+	const uint64_t* mip_sizes;
+} pt_texture_desc_t;
+
+/* sampling_strategy_t at src/main.h:83-94 */
+enum {
+	PT_SAMPLING_STRATEGY_SPHERICAL = 0,
+	PT_SAMPLING_STRATEGY_PSA = 1,
+	PT_SAMPLING_STRATEGY_BRDF = 2,
+	PT_SAMPLING_STRATEGY_NEE = 3,
+};
+
+typedef struct pt_scene pt_scene_t;
+
+/* Uploads a scene and builds its BVH on the GPU. Replaces load_scene() at
+ * src/scene.c:282-404 from the point where the file has been read: the three
+ * mesh arrays of src/scene.h:24-38 (positions: 3 x 2 uint32 per triangle,
+ * normals_and_tex_coords: 3 x 4 uint16 per triangle, material_indices: 1
+ * uint8 per triangle), create_bvh() at src/scene.c:90-264 and the texture
+ * upload of load_textures() at src/textures.c:112-167. textures holds three
+ * entries per material (base colour, specular, normal; src/scene.h:41-59).
+ * device_index selects the GPU. On failure *out_scene is NULL. */
+int pt_create_scene(pt_scene_t** out_scene, int device_index, const pt_scene_header_t* header,
+	const uint32_t* positions, const uint16_t* normals_and_tex_coords, const uint8_t* material_indices,
+	const pt_texture_desc_t* textures, uint32_t texture_count);
+
+/* free_scene() at src/scene.c:407-420. NULL is allowed. */
+void pt_destroy_scene(pt_scene_t* scene);
+
+/* Replaces lit_scene_t.spherical_lights (src/main.h:276-283, filled at
+ * src/main.c:687-698): count lights of four floats (x, y, z, radius). Unlike
+ * the reference there is no limit of 32; the spherical_lights member of
+ * pt_constants_t is ignored. */
+int pt_set_lights(pt_scene_t* scene, const float* lights, uint32_t count);
+
+/* Replaces the shader defines SAMPLING_STRATEGY_*, PATH_LENGTH and
+ * EMISSION_MATERIAL_INDEX of src/main.c:936-949 (render_settings_t at
+ * src/main.h:99-105). path_length is at most 16. */
+int pt_set_render_settings(pt_scene_t* scene, int sampling_strategy, uint32_t path_length, uint32_t emission_material_index);
+
+/* create_render_targets() at src/main.c:519-560: allocates the RGBA32F
+ * accumulation target and the wavefront buffers for this resolution and
+ * resets the accumulated sample count. */
+int pt_create_render_targets(pt_scene_t* scene, uint32_t width, uint32_t height);
+
+/* Renders sample_count frames; sample s uses g_frame_index =
+ * first_frame_index + s * frame_stride. Replaces the per-frame uniform
+ * upload and draw of record_render_frame_commands() at
+ * src/main.c:1842-1891: the first frame overwrites the target when
+ * accumulate is 0 (pipeline_discard), all others add to it (blend ONE, ONE,
+ * alpha stays 1; src/main.c:1000-1021,1884-1888). Returns once the work is
+ * queued; pt_synchronize() or pt_read_accumulation() wait for it. */
+int pt_render_samples(pt_scene_t* scene, const pt_constants_t* constants,
+	uint32_t first_frame_index, uint32_t sample_count, uint32_t frame_stride, int accumulate);
+
+/* Waits for all queued work of this scene. */
+int pt_synchronize(pt_scene_t* scene);
+
+/* Copies the accumulation target to the host: width * height RGBA floats,
+ * row-major from the top-left pixel, the sum (not the mean) over all
+ * accumulated frames with alpha 1, as save_screenshot() finds it at
+ * src/main.c:2043-2051. *out_sample_count receives the number of frames
+ * accumulated (render_targets_t.accum_frame_count). Either may be NULL. */
+int pt_read_accumulation(pt_scene_t* scene, float* rgba, uint32_t* out_sample_count);
+
+/* The device address of the accumulation target (width * height * 4
+ * floats) and a way to adjust the sample count, for hosts that sum the
+ * targets of several GPUs themselves (RCCL all-reduce). No counterpart in
+ * the reference, which is single-GPU. */
+void* pt_get_accumulation_device_pointer(pt_scene_t* scene);
+int pt_set_sample_count(pt_scene_t* scene, uint32_t sample_count);
+
+/* Counters and timings since the last reset. Ray counts are the numbers of
+ * extension and shadow rays actually traced (queue sizes). Node and triangle
+ * visits are only counted while profiling is enabled. Kernel times are sums
+ * of HIP event intervals on the library's stream, recorded only while timing
+ * is enabled. No counterpart in the reference besides the two timestamps
+ * around its draw (src/main.c:1890-1892). */
+typedef struct {
+	uint64_t extension_rays;
+	uint64_t shadow_rays;
+	uint64_t paths;
+	uint64_t nodes_visited;
+	uint64_t triangles_tested;
+	uint64_t shaded_hits;
+	/* index: 0 raygen, 1 extension trace, 2 shadow trace, 3 shade, 4 resolve */
+	double kernel_ms[5];
+	uint64_t kernel_launches[5];
+} pt_statistics_t;
+int pt_set_instrumentation(pt_scene_t* scene, int enable_kernel_timing, int enable_visit_counters);
+int pt_get_statistics(pt_scene_t* scene, pt_statistics_t* out_statistics);
+int pt_reset_statistics(pt_scene_t* scene);
+
+/* Facts about the BVH that was built (sizes of its arrays in HBM). */
+typedef struct {
+	uint32_t node_count;
+	uint32_t triangle_count;
+	uint32_t depth;
+	uint32_t node_bytes;
+	uint32_t triangle_bytes;
+	float build_ms;
+} pt_bvh_info_t;
+int pt_get_bvh_info(pt_scene_t* scene, pt_bvh_info_t* out_info);
+
+/* Test hooks: the closest hit of every primary ray of one frame in pixel
+ * order (what rayQueryGetIntersection*EXT return at
+ * src/shaders/pathtrace.frag.glsl:187-195), and of caller-supplied rays
+ * (origin and direction, 3 floats each; tmin 1e-3, tmax 1e38).
+ * triangle_indices receives -1 for a miss; t_u_v three floats per ray. */
+int pt_trace_primary_rays(pt_scene_t* scene, const pt_constants_t* constants, uint32_t frame_index,
+	int32_t* triangle_indices, float* barycentrics, uint8_t* front);
+int pt_trace_rays(pt_scene_t* scene, const float* origins, const float* directions, uint32_t ray_count,
+	int32_t* triangle_indices, float* t_u_v, uint8_t* front);
+
+/* Test hook: get_shading_data() of src/shaders/shading_data.glsl:51-103 for
+ * given hits; 20 floats per hit in the member order of shading_data_t. */
+int pt_evaluate_shading_data(pt_scene_t* scene, const pt_constants_t* constants,
+	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs,
+	uint32_t count, float* out_shading_data);
+
+/* Test hook: the first draw_count pairs of get_random_numbers()
+ * (src/shaders/pathtrace.frag.glsl:23-34) for the seed of pixel (x, y) in
+ * frame frame_index (:368), computed on the GPU. */
+int pt_random_numbers(int device_index, uint32_t x, uint32_t y, uint32_t frame_index, uint32_t draw_count, float* out_randoms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

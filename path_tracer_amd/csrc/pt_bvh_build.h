@@ -1,0 +1,363 @@
+// GPU construction of the 8-wide compressed BVH that replaces the Vulkan
+// acceleration structure build of the reference (src/scene.c:32-82,90-264):
+//   1. dequantise vertices exactly like the reference's CPU loop (separate
+//      multiply and add, src/scene.c:43-55) and find the scene bounds,
+//   2. 63-bit Morton codes of triangle centroids, radix sort,
+//   3. binary radix tree over the sorted codes (Karras, HPG 2012),
+//   4. bottom-up bounding boxes with one atomic counter per inner node,
+//   5. top-down collapse into 8-wide nodes, opening the child with the
+//      largest surface area first, child boxes quantised to 8 bits, children
+//      placed in slots so that slot ^ ray octant orders them front to back.
+// Each step is a per-thread function; the kernels that run them are in
+// pt_hip.hip.
+#pragma once
+#include "pt_common.h"
+
+struct PtBuild {
+	uint32_t n; // triangle count
+	const u32x2* positions;
+	float factor[3], summand[3];
+	float* verts;        // 9 floats per triangle, file order
+	uint32_t* bounds;    // 6 order-preserving uint keys: min xyz, max xyz
+	uint64_t* keys;      // Morton codes
+	uint32_t* order;     // triangle index per sorted position
+	// binary radix tree: inner nodes 0 .. n-2, leaf k is node n-1+k
+	uint32_t* left;
+	uint32_t* right;
+	uint32_t* parent;    // per node (inner and leaf)
+	uint32_t* range_first;
+	uint32_t* range_last;
+	float* box;          // 6 floats per node (inner and leaf)
+	uint32_t* flags;     // per inner node
+	// wide BVH
+	PtNode* nodes;
+	PtTri* tris;
+	uint32_t* task_binary; // binary node that wide node i collapses
+	uint32_t* counters;    // [0] wide nodes allocated, [1] triangles written
+};
+
+// Order-preserving map from float to uint so that integer atomics can
+// compute float minima and maxima
+PT_FN uint32_t pt_float_to_key(float f) {
+	uint32_t u = pt_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+PT_FN float pt_key_to_float(uint32_t k) {
+	return pt_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// Step 1: vertex arithmetic of src/scene.c:43-55
+PT_FN void pt_build_dequantize(const PtBuild& b, uint32_t tri, float out_lo[3], float out_hi[3]) {
+	for (int j = 0; j != 3; ++j) { out_lo[j] = INFINITY; out_hi[j] = -INFINITY; }
+	for (uint32_t v = 0; v != 3; ++v) {
+		u32x2 q = b.positions[3 * (uint64_t) tri + v];
+		float pos[3] = {
+			(float) (q.x & 0x1fffffu),
+			(float) (((q.x & 0xffe00000u) >> 21) | ((q.y & 0x3ffu) << 11)),
+			(float) ((q.y & 0x7ffffc00u) >> 10),
+		};
+		for (int j = 0; j != 3; ++j) {
+			float w = pos[j] * b.factor[j] + b.summand[j];
+			b.verts[9 * (uint64_t) tri + 3 * v + j] = w;
+			out_lo[j] = fminf(out_lo[j], w);
+			out_hi[j] = fmaxf(out_hi[j], w);
+		}
+	}
+}
+
+struct PtSceneBounds { float lo[3], hi[3], pad; };
+
+PT_FN PtSceneBounds pt_build_get_bounds(const uint32_t* keys) {
+	PtSceneBounds r;
+	float max_abs = 0.0f;
+	for (int j = 0; j != 3; ++j) {
+		r.lo[j] = pt_key_to_float(keys[j]);
+		r.hi[j] = pt_key_to_float(keys[3 + j]);
+		max_abs = fmaxf(max_abs, fmaxf(fabsf(r.lo[j]), fabsf(r.hi[j])));
+	}
+	// Boxes are padded by this much so that rounding in the ray/box test can
+	// never cull a triangle that the ray/triangle test would accept
+	r.pad = max_abs * 1.9073486328125e-06f;
+	return r;
+}
+
+PT_FN void pt_tri_box(const float* verts, float pad, float lo[3], float hi[3]) {
+	for (int j = 0; j != 3; ++j) {
+		float v0 = verts[j], v1 = verts[3 + j], v2 = verts[6 + j];
+		lo[j] = fminf(v0, fminf(v1, v2)) - pad;
+		hi[j] = fmaxf(v0, fmaxf(v1, v2)) + pad;
+	}
+}
+
+PT_FN uint64_t pt_spread_bits_21(uint64_t v) {
+	v &= 0x1fffffull;
+	v = (v | (v << 32)) & 0x1f00000000ffffull;
+	v = (v | (v << 16)) & 0x1f0000ff0000ffull;
+	v = (v | (v << 8)) & 0x100f00f00f00f00full;
+	v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+	v = (v | (v << 2)) & 0x1249249249249249ull;
+	return v;
+}
+
+// Step 2
+PT_FN uint64_t pt_build_morton(const PtBuild& b, const PtSceneBounds& sb, uint32_t tri) {
+	float lo[3], hi[3];
+	pt_tri_box(&b.verts[9 * (uint64_t) tri], 0.0f, lo, hi);
+	uint64_t code = 0;
+	for (int j = 0; j != 3; ++j) {
+		float extent = sb.hi[j] - sb.lo[j];
+		float c = 0.5f * (lo[j] + hi[j]);
+		float t = (extent > 0.0f) ? (c - sb.lo[j]) / extent : 0.0f;
+		t = fminf(fmaxf(t * 2097152.0f, 0.0f), 2097151.0f);
+		code |= pt_spread_bits_21((uint64_t) t) << j;
+	}
+	return code;
+}
+
+PT_FN int pt_clz64(uint64_t v) { return v ? __builtin_clzll(v) : 64; }
+PT_FN int pt_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+PT_FN int pt_popc(uint32_t v) { return __builtin_popcount(v); }
+
+// Length of the common prefix of the keys at sorted positions i and j, with
+// the position as tie breaker for equal keys; -1 outside the array
+PT_FN int pt_build_delta(const PtBuild& b, int i, int j) {
+	if (j < 0 || j >= (int) b.n)
+		return -1;
+	uint64_t x = b.keys[i] ^ b.keys[j];
+	if (x == 0)
+		return 64 + pt_clz32((uint32_t) i ^ (uint32_t) j);
+	return pt_clz64(x);
+}
+
+// Step 3: inner node i of the binary radix tree
+PT_FN void pt_build_radix_tree(const PtBuild& b, uint32_t index) {
+	int i = (int) index;
+	int d = (pt_build_delta(b, i, i + 1) - pt_build_delta(b, i, i - 1)) >= 0 ? 1 : -1;
+	int delta_min = pt_build_delta(b, i, i - d);
+	int l_max = 2;
+	while (pt_build_delta(b, i, i + l_max * d) > delta_min)
+		l_max *= 2;
+	int l = 0;
+	for (int t = l_max / 2; t >= 1; t /= 2)
+		if (pt_build_delta(b, i, i + (l + t) * d) > delta_min)
+			l += t;
+	int j = i + l * d;
+	int delta_node = pt_build_delta(b, i, j);
+	int s = 0;
+	int t = l;
+	do {
+		t = (t + 1) >> 1;
+		if (pt_build_delta(b, i, i + (s + t) * d) > delta_node)
+			s += t;
+	} while (t > 1);
+	int gamma = i + s * d + ((d < 0) ? -1 : 0);
+	int first = (i < j) ? i : j, last = (i < j) ? j : i;
+	uint32_t leaf_base = b.n - 1;
+	uint32_t left = (first == gamma) ? leaf_base + (uint32_t) gamma : (uint32_t) gamma;
+	uint32_t right = (last == gamma + 1) ? leaf_base + (uint32_t) (gamma + 1) : (uint32_t) (gamma + 1);
+	b.left[i] = left;
+	b.right[i] = right;
+	b.parent[left] = index;
+	b.parent[right] = index;
+	b.range_first[i] = (uint32_t) first;
+	b.range_last[i] = (uint32_t) last;
+	if (i == 0)
+		b.parent[0] = 0xffffffffu;
+}
+
+// Step 4: called once per leaf (sorted position k). Writes the leaf box, then
+// climbs: the second thread to reach an inner node merges its children's
+// boxes. arrive(flag_ptr) must be an atomic increment that returns the old
+// value and orders this thread's earlier box stores before it and its later
+// box loads after it (release/acquire at device scope).
+template <typename Arrive>
+PT_FN void pt_build_refit(const PtBuild& b, float pad, uint32_t k, Arrive arrive) {
+	uint32_t node = b.n - 1 + k;
+	float* box = &b.box[6 * (uint64_t) node];
+	float lo[3], hi[3];
+	pt_tri_box(&b.verts[9 * (uint64_t) b.order[k]], pad, lo, hi);
+	for (int j = 0; j != 3; ++j) { box[j] = lo[j]; box[3 + j] = hi[j]; }
+	if (b.n < 2)
+		return;
+	uint32_t parent = b.parent[node];
+	while (parent != 0xffffffffu) {
+		if (arrive(&b.flags[parent]) == 0)
+			return;
+		const float* l = &b.box[6 * (uint64_t) b.left[parent]];
+		const float* r = &b.box[6 * (uint64_t) b.right[parent]];
+		float* out = &b.box[6 * (uint64_t) parent];
+		for (int j = 0; j != 3; ++j) {
+			out[j] = fminf(l[j], r[j]);
+			out[3 + j] = fmaxf(l[j + 3], r[j + 3]);
+		}
+		parent = b.parent[parent];
+	}
+}
+
+// Surface area of a box given as 6 floats (only compared, never output)
+PT_FN float pt_box_area(const float* box) {
+	float dx = box[3] - box[0], dy = box[4] - box[1], dz = box[5] - box[2];
+	return (dx * dy + dy * dz) + dz * dx;
+}
+
+PT_FN uint32_t pt_build_range_size(const PtBuild& b, uint32_t node) {
+	if (node >= b.n - 1)
+		return 1;
+	return b.range_last[node] - b.range_first[node] + 1;
+}
+
+PT_FN uint32_t pt_build_range_first(const PtBuild& b, uint32_t node) {
+	if (node >= b.n - 1)
+		return node - (b.n - 1);
+	return b.range_first[node];
+}
+
+// Power of two with biased exponent e, and the smallest e such that
+// extent / 2^(e-127) rounds up to at most 255
+PT_FN float pt_exp2_biased(uint32_t e) { return pt_as_float(e << 23); }
+PT_FN uint32_t pt_quantization_exponent(float extent) {
+	// extent / 255 <= 2^(e-127); start from the exponent of extent / 255
+	float target = extent * (1.0f / 255.0f);
+	uint32_t e = (pt_as_uint(target) >> 23) & 0xffu;
+	if (e < 1) e = 1;
+	// round up to the next power of two unless target is one already
+	if ((pt_as_uint(target) & 0x007fffffu) != 0 || e == 1) e += 1;
+	while (e < 254 && ceilf(extent / pt_exp2_biased(e)) > 255.0f) ++e;
+	return e;
+}
+
+// Step 5: builds wide node wide_index from the binary subtree rooted at
+// b.task_binary[wide_index]. alloc_nodes(count) / alloc_tris(count) reserve
+// consecutive wide nodes / triangle slots and return the first index.
+template <typename AllocNodes, typename AllocTris>
+PT_FN void pt_build_collapse(const PtBuild& b, float pad, uint32_t wide_index, AllocNodes alloc_nodes, AllocTris alloc_tris) {
+	uint32_t children[8];
+	uint32_t count;
+	uint32_t root = b.task_binary[wide_index];
+	if (pt_build_range_size(b, root) <= 3) {
+		children[0] = root;
+		count = 1;
+	}
+	else {
+		children[0] = b.left[root];
+		children[1] = b.right[root];
+		count = 2;
+		while (count < 8) {
+			int best = -1;
+			float best_area = -1.0f;
+			for (uint32_t c = 0; c != count; ++c) {
+				if (pt_build_range_size(b, children[c]) <= 3)
+					continue;
+				float area = pt_box_area(&b.box[6 * (uint64_t) children[c]]);
+				if (area > best_area) {
+					best_area = area;
+					best = (int) c;
+				}
+			}
+			if (best < 0)
+				break;
+			uint32_t open = children[best];
+			children[best] = b.left[open];
+			children[count++] = b.right[open];
+		}
+	}
+	// Node frame
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	for (uint32_t c = 0; c != count; ++c) {
+		const float* box = &b.box[6 * (uint64_t) children[c]];
+		for (int j = 0; j != 3; ++j) {
+			lo[j] = fminf(lo[j], box[j]);
+			hi[j] = fmaxf(hi[j], box[3 + j]);
+		}
+	}
+	PtNode node;
+	memset(&node, 0, sizeof(node));
+	float scale[3];
+	for (int j = 0; j != 3; ++j) {
+		node.origin[j] = lo[j];
+		uint32_t e = pt_quantization_exponent(hi[j] - lo[j]);
+		node.exponent[j] = (uint8_t) e;
+		scale[j] = pt_exp2_biased(e);
+	}
+	// Greedy assignment of children to slots: slot s prefers children lying
+	// towards the low side of every axis whose bit is clear in s, so that
+	// slot ^ (7 - ray octant) enumerates the children roughly front to back
+	float center[3] = { 0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]) };
+	int slot_of[8], child_in_slot[8];
+	for (int i = 0; i != 8; ++i) { slot_of[i] = -1; child_in_slot[i] = -1; }
+	for (uint32_t round = 0; round != count; ++round) {
+		float best_cost = -INFINITY;
+		int best_c = -1, best_s = -1;
+		for (uint32_t c = 0; c != count; ++c) {
+			if (slot_of[c] >= 0)
+				continue;
+			const float* box = &b.box[6 * (uint64_t) children[c]];
+			float dx = 0.5f * (box[0] + box[3]) - center[0];
+			float dy = 0.5f * (box[1] + box[4]) - center[1];
+			float dz = 0.5f * (box[2] + box[5]) - center[2];
+			for (int s = 0; s != 8; ++s) {
+				if (child_in_slot[s] >= 0)
+					continue;
+				float cost = (((s & 1) ? dx : -dx) + ((s & 2) ? dy : -dy)) + ((s & 4) ? dz : -dz);
+				if (cost > best_cost) {
+					best_cost = cost;
+					best_c = (int) c;
+					best_s = s;
+				}
+			}
+		}
+		slot_of[best_c] = best_s;
+		child_in_slot[best_s] = best_c;
+	}
+	// Count inner children and triangles, reserve their storage
+	uint32_t inner_count = 0, tri_count = 0;
+	for (int s = 0; s != 8; ++s) {
+		if (child_in_slot[s] < 0)
+			continue;
+		uint32_t size = pt_build_range_size(b, children[child_in_slot[s]]);
+		if (size <= 3)
+			tri_count += size;
+		else {
+			++inner_count;
+			node.imask |= (uint8_t) (1u << s);
+		}
+	}
+	node.child_base = inner_count ? alloc_nodes(inner_count) : 0;
+	node.tri_base = tri_count ? alloc_tris(tri_count) : 0;
+	uint32_t inner_offset = 0, tri_offset = 0;
+	for (int s = 0; s != 8; ++s) {
+		if (child_in_slot[s] < 0)
+			continue;
+		uint32_t child = children[child_in_slot[s]];
+		const float* box = &b.box[6 * (uint64_t) child];
+		for (int j = 0; j != 3; ++j) {
+			float qlo = floorf((box[j] - node.origin[j]) / scale[j]);
+			float qhi = ceilf((box[3 + j] - node.origin[j]) / scale[j]);
+			node.qlo[j][s] = (uint8_t) fminf(fmaxf(qlo, 0.0f), 255.0f);
+			node.qhi[j][s] = (uint8_t) fminf(fmaxf(qhi, 0.0f), 255.0f);
+		}
+		uint32_t size = pt_build_range_size(b, child);
+		if (size <= 3) {
+			uint32_t first = pt_build_range_first(b, child);
+			for (uint32_t t = 0; t != size; ++t) {
+				uint32_t tri = b.order[first + t];
+				PtTri out;
+				const float* v = &b.verts[9 * (uint64_t) tri];
+				for (int j = 0; j != 3; ++j) { out.v0[j] = v[j]; out.v1[j] = v[3 + j]; out.v2[j] = v[6 + j]; }
+				out.prim = tri;
+				out.pad[0] = out.pad[1] = 0;
+				b.tris[node.tri_base + tri_offset + t] = out;
+			}
+			uint32_t unary = (1u << size) - 1u;
+			node.meta[s] = (uint8_t) ((unary << 5) | tri_offset);
+			tri_offset += size;
+		}
+		else {
+			node.meta[s] = (uint8_t) (0x20u | (24u + (uint32_t) s));
+			b.task_binary[node.child_base + inner_offset] = child;
+			++inner_offset;
+		}
+	}
+	(void) pad;
+	b.nodes[wide_index] = node;
+}

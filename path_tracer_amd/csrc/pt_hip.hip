@@ -1,0 +1,1234 @@
+// MI355X (gfx950) kernels and the C ABI of the light transport library.
+//
+// Wavefront organisation of the reference's fragment shader
+// (src/shaders/pathtrace.frag.glsl): one batch holds all pixels of one or
+// more frames as independent paths. Per batch:
+//   raygen                      seeds, pixel jitter, camera rays (:365-386)
+//   for every path vertex k:    (loop bodies of :224-362)
+//     trace extension rays      closest hits via the 8-wide BVH (:181-199)
+//     shade                     shading data, emission, NEE + BRDF sampling
+//     trace shadow rays         closest hit, emission of what was hit (:203-219)
+//   resolve                     frame-ordered sum into the RGBA32F target
+// Queues of rays live in HBM as structure-of-arrays float4 streams; surviving
+// paths are compacted with a wave ballot and one atomic per wave.
+#include "pt_common.h"
+#include "pt_bvh_build.h"
+#include "pt_trace.h"
+#include "pt_shade.h"
+#include "../../include/pt_hip.h"
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device constants must agree");
+
+#define PT_BLOCK 256
+#define PT_LDS_STACK 12
+#define PT_INVALID 0xffffffffu
+
+#define PT_CHECK(call) do { hipError_t pt_err_ = (call); if (pt_err_ != hipSuccess) { \
+	printf("HIP error %s at %s:%d (%s).\n", hipGetErrorString(pt_err_), __FILE__, __LINE__, #call); return 1; } } while (0)
+
+
+// ---------------------------------------------------------------- BVH build
+
+__device__ __forceinline__ float pt_wave_min(float v) {
+	for (int offset = 32; offset; offset >>= 1)
+		v = fminf(v, __shfl_xor(v, offset));
+	return v;
+}
+__device__ __forceinline__ float pt_wave_max(float v) {
+	for (int offset = 32; offset; offset >>= 1)
+		v = fmaxf(v, __shfl_xor(v, offset));
+	return v;
+}
+
+__global__ void __launch_bounds__(PT_BLOCK) k_build_dequantize(PtBuild b) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+	if (i < b.n)
+		pt_build_dequantize(b, i, lo, hi);
+	for (int j = 0; j != 3; ++j) {
+		float l = pt_wave_min(lo[j]), h = pt_wave_max(hi[j]);
+		if ((threadIdx.x & 63) == 0) {
+			atomicMin(&b.bounds[j], pt_float_to_key(l));
+			atomicMax(&b.bounds[3 + j], pt_float_to_key(h));
+		}
+	}
+}
+
+__global__ void __launch_bounds__(PT_BLOCK) k_build_morton(PtBuild b) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i >= b.n)
+		return;
+	PtSceneBounds sb = pt_build_get_bounds(b.bounds);
+	b.keys[i] = pt_build_morton(b, sb, i);
+	b.order[i] = i;
+}
+
+__global__ void __launch_bounds__(PT_BLOCK) k_build_radix_tree(PtBuild b) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i + 1 < b.n)
+		pt_build_radix_tree(b, i);
+}
+
+__global__ void __launch_bounds__(PT_BLOCK) k_build_refit(PtBuild b) {
+	uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (k >= b.n)
+		return;
+	PtSceneBounds sb = pt_build_get_bounds(b.bounds);
+	pt_build_refit(b, sb.pad, k, [](uint32_t* flag) {
+		__threadfence();
+		uint32_t old = atomicAdd(flag, 1u);
+		__threadfence();
+		return old;
+	});
+}
+
+__global__ void __launch_bounds__(PT_BLOCK) k_build_collapse(PtBuild b, uint32_t level_begin, uint32_t level_end) {
+	uint32_t i = level_begin + blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i >= level_end)
+		return;
+	PtSceneBounds sb = pt_build_get_bounds(b.bounds);
+	pt_build_collapse(b, sb.pad, i,
+		[&](uint32_t count) { return atomicAdd(&b.counters[0], count); },
+		[&](uint32_t count) { return atomicAdd(&b.counters[1], count); });
+}
+
+
+// ---------------------------------------------------------------- wavefront
+
+// Blocks are dealt round-robin to the 8 XCDs, each with its own L2. Giving
+// XCD x the x-th contiguous eighth of a queue keeps rays that started as
+// neighbouring pixels on one L2. Returns false for surplus blocks.
+__device__ __forceinline__ bool pt_block_first_slot(uint32_t count, uint32_t* out_first_slot) {
+	uint32_t block_count = (count + PT_BLOCK - 1) / PT_BLOCK;
+	uint32_t chunk = (block_count + 7) / 8;
+	uint32_t group = blockIdx.x & 7, j = blockIdx.x >> 3;
+	uint32_t virtual_block = group * chunk + j;
+	if (j >= chunk || virtual_block >= block_count)
+		return false;
+	*out_first_slot = virtual_block * PT_BLOCK;
+	return true;
+}
+
+// Reserves one queue slot for every lane with want set: one atomic per wave
+__device__ __forceinline__ uint32_t pt_wave_push(uint32_t* counter, bool want) {
+	unsigned long long mask = __ballot(want);
+	uint32_t total = (uint32_t) __popcll(mask);
+	uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+	uint32_t base = 0;
+	if (total) {
+		uint32_t leader = (uint32_t) __builtin_ctzll(mask);
+		if ((threadIdx.x & 63) == leader)
+			base = atomicAdd(counter, total);
+		base = (uint32_t) __shfl((int) base, (int) leader);
+	}
+	return base + prefix;
+}
+
+// Short traversal stack: the first PT_LDS_STACK entries of every lane live
+// in LDS (entry-major, so a wave's accesses are consecutive 8-byte words),
+// deeper entries in a global overflow buffer laid out the same way.
+struct PtGpuStack {
+	u32x2* lds;
+	u32x2* overflow;
+	uint32_t overflow_stride, capacity;
+	uint32_t sp;
+	__device__ __forceinline__ void push(u32x2 e) {
+		if (sp < PT_LDS_STACK)
+			lds[sp * PT_BLOCK] = e;
+		else if (sp < capacity)
+			overflow[(uint64_t) (sp - PT_LDS_STACK) * overflow_stride] = e;
+		else
+			return;
+		++sp;
+	}
+	__device__ __forceinline__ u32x2 pop() {
+		--sp;
+		return (sp < PT_LDS_STACK) ? lds[sp * PT_BLOCK] : overflow[(uint64_t) (sp - PT_LDS_STACK) * overflow_stride];
+	}
+	__device__ __forceinline__ bool empty() const { return sp == 0; }
+};
+
+struct PtTraceArgs {
+	PtSceneView scene;
+	PtWavefront wf;
+	const PtConstants* constants;
+	u32x2* stack_overflow;
+	uint32_t stack_overflow_stride, stack_capacity;
+	uint32_t bounce;  // index into ext_count / shadow_count
+	uint32_t parity;  // which ray queue holds this bounce
+	unsigned long long* visit_counters; // [0] nodes, [1] triangles, or NULL
+};
+
+// pathtrace.frag.glsl:365-386 for every path of the batch
+__global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtConstants* constants, PtWavefront wf, uint32_t path_count) {
+	uint32_t p = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (p >= path_count)
+		return;
+	uint32_t x, y, frame_slot;
+	bool inside = pt_path_to_pixel(batch, p, &x, &y, &frame_slot);
+	uint32_t sx = 0, sy = 0;
+	v3 origin = mk3(0.0f, 0.0f, 0.0f), dir = mk3(0.0f, 0.0f, 1.0f);
+	if (inside)
+		pt_primary_ray(*constants, x, y, batch.first_frame_index + frame_slot * batch.frame_stride, sx, sy, &origin, &dir);
+	wf.ray_o[0][p] = mk4(origin.x, origin.y, origin.z, pt_as_float(inside ? p : PT_INVALID));
+	wf.ray_d[0][p] = mk4(dir.x, dir.y, dir.z, 0.0f);
+	wf.state0[p] = mk4(1.0f, 1.0f, 1.0f, pt_as_float(sx));
+	wf.state1[p] = mk4(1.0f, 1.0f, 1.0f, pt_as_float(sy));
+	wf.radiance[p] = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+	if (p == 0)
+		wf.ext_count[0] = path_count;
+}
+
+// trace_ray() of pathtrace.frag.glsl:181-199 up to the hit record
+template <bool COUNT_VISITS>
+__global__ void __launch_bounds__(PT_BLOCK) k_trace_extension(PtTraceArgs a) {
+	__shared__ u32x2 lds_stack[PT_LDS_STACK * PT_BLOCK];
+	uint32_t first_slot;
+	uint32_t count = a.wf.ext_count[a.bounce];
+	if (!pt_block_first_slot(count, &first_slot))
+		return;
+	uint32_t slot = first_slot + threadIdx.x;
+	if (slot >= count)
+		return;
+	f32x4 o = a.wf.ray_o[a.parity][slot], d = a.wf.ray_d[a.parity][slot];
+	PtHit hit;
+	hit.prim = PT_INVALID;
+	hit.t = 1e38f;
+	hit.u = hit.v = 0.0f;
+	hit.front = false;
+	if (pt_as_uint(o.w) != PT_INVALID) {
+		PtGpuStack stack;
+		stack.lds = &lds_stack[threadIdx.x];
+		stack.overflow = a.stack_overflow + (blockIdx.x * PT_BLOCK + threadIdx.x);
+		stack.overflow_stride = a.stack_overflow_stride;
+		stack.capacity = a.stack_capacity;
+		stack.sp = 0;
+		uint32_t visits[2] = { 0, 0 };
+		hit = pt_trace_closest<COUNT_VISITS>(a.scene.nodes, a.scene.tris, a.scene.triangle_count, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 1.0e-3f, 1e38f, stack, visits);
+		if (COUNT_VISITS) {
+			atomicAdd(&a.visit_counters[0], (unsigned long long) visits[0]);
+			atomicAdd(&a.visit_counters[1], (unsigned long long) visits[1]);
+		}
+	}
+	u32x4 record;
+	record.x = hit.prim;
+	record.y = pt_as_uint(hit.u);
+	record.z = pt_as_uint(hit.v);
+	record.w = hit.front ? 1u : 0u;
+	a.wf.hit[slot] = record;
+}
+
+// trace_ray_emission() of pathtrace.frag.glsl:203-219 and the MIS sum at :338
+template <bool COUNT_VISITS>
+__global__ void __launch_bounds__(PT_BLOCK) k_trace_shadow(PtTraceArgs a) {
+	__shared__ u32x2 lds_stack[PT_LDS_STACK * PT_BLOCK];
+	uint32_t first_slot;
+	uint32_t count = a.wf.shadow_count[a.bounce];
+	if (!pt_block_first_slot(count, &first_slot))
+		return;
+	uint32_t slot = first_slot + threadIdx.x;
+	if (slot >= count)
+		return;
+	f32x4 o = a.wf.sh_o[slot], d = a.wf.sh_d[slot], w = a.wf.sh_w[slot];
+	PtGpuStack stack;
+	stack.lds = &lds_stack[threadIdx.x];
+	stack.overflow = a.stack_overflow + (blockIdx.x * PT_BLOCK + threadIdx.x);
+	stack.overflow_stride = a.stack_overflow_stride;
+	stack.capacity = a.stack_capacity;
+	stack.sp = 0;
+	uint32_t visits[2] = { 0, 0 };
+	PtHit hit = pt_trace_closest<COUNT_VISITS>(a.scene.nodes, a.scene.tris, a.scene.triangle_count, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 1.0e-3f, 1e38f, stack, visits);
+	if (COUNT_VISITS) {
+		atomicAdd(&a.visit_counters[0], (unsigned long long) visits[0]);
+		atomicAdd(&a.visit_counters[1], (unsigned long long) visits[1]);
+	}
+	const PtConstants& c = *a.constants;
+	v3 emission;
+	if (hit.prim == PT_INVALID)
+		emission = mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
+	else if (a.scene.materials[hit.prim] == a.scene.emission_material_index)
+		emission = mk3(c.emission_material_radiance[0], c.emission_material_radiance[1], c.emission_material_radiance[2]);
+	else
+		emission = mk3(0.0f, 0.0f, 0.0f);
+	uint32_t path = pt_as_uint(o.w);
+	f32x4 radiance = a.wf.radiance[path];
+	v3 sum = mk3(radiance.x, radiance.y, radiance.z) + (mk3(w.x, w.y, w.z) * emission) * d.w;
+	a.wf.radiance[path] = mk4(sum.x, sum.y, sum.z, 0.0f);
+}
+
+struct PtShadeArgs {
+	PtSceneView scene;
+	PtWavefront wf;
+	const PtConstants* constants;
+	int strategy;
+	uint32_t path_length;
+	uint32_t k;       // 1-based path vertex; reads ext queue k - 1
+	uint32_t parity;  // ray queue of this bounce; the next one is parity ^ 1
+	unsigned long long* visit_counters; // [2] counts shaded hits, or NULL
+};
+
+__global__ void __launch_bounds__(PT_BLOCK) k_shade(PtShadeArgs a) {
+	uint32_t first_slot;
+	uint32_t count = a.wf.ext_count[a.k - 1];
+	if (!pt_block_first_slot(count, &first_slot))
+		return;
+	uint32_t slot = first_slot + threadIdx.x;
+	bool active = slot < count;
+	uint32_t path = PT_INVALID;
+	PtVertexResult r;
+	r.continues = false;
+	r.shadow = false;
+	if (active) {
+		f32x4 o = a.wf.ray_o[a.parity][slot];
+		path = pt_as_uint(o.w);
+		active = path != PT_INVALID;
+	}
+	if (active) {
+		f32x4 d = a.wf.ray_d[a.parity][slot];
+		u32x4 hit = a.wf.hit[slot];
+		f32x4 s0 = a.wf.state0[path], s1 = a.wf.state1[path], rad = a.wf.radiance[path];
+		v3 throughput = mk3(s0.x, s0.y, s0.z), nee_throughput = mk3(s1.x, s1.y, s1.z), radiance = mk3(rad.x, rad.y, rad.z);
+		uint32_t sx = pt_as_uint(s0.w), sy = pt_as_uint(s1.w);
+		if (a.visit_counters && hit.x != PT_INVALID)
+			atomicAdd(&a.visit_counters[2], 1ull);
+		r = pt_shade_vertex(a.scene, *a.constants, a.strategy, a.path_length, a.k,
+			hit.x, pt_as_float(hit.y), pt_as_float(hit.z), hit.w != 0, mk3(d.x, d.y, d.z),
+			radiance, throughput, nee_throughput, sx, sy);
+		a.wf.radiance[path] = mk4(radiance.x, radiance.y, radiance.z, 0.0f);
+		if (r.continues) {
+			a.wf.state0[path] = mk4(throughput.x, throughput.y, throughput.z, pt_as_float(sx));
+			a.wf.state1[path] = mk4(nee_throughput.x, nee_throughput.y, nee_throughput.z, pt_as_float(sy));
+		}
+	}
+	// Compact survivors into the next queues (whole waves take part)
+	uint32_t next_slot = pt_wave_push(&a.wf.ext_count[a.k], r.continues);
+	if (r.continues) {
+		a.wf.ray_o[a.parity ^ 1][next_slot] = mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path));
+		a.wf.ray_d[a.parity ^ 1][next_slot] = mk4(r.next_dir.x, r.next_dir.y, r.next_dir.z, 0.0f);
+	}
+	uint32_t shadow_slot = pt_wave_push(&a.wf.shadow_count[a.k], r.shadow);
+	if (r.shadow) {
+		a.wf.sh_o[shadow_slot] = mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path));
+		a.wf.sh_d[shadow_slot] = mk4(r.shadow_dir.x, r.shadow_dir.y, r.shadow_dir.z, r.shadow_factor);
+		a.wf.sh_w[shadow_slot] = mk4(r.shadow_weight.x, r.shadow_weight.y, r.shadow_weight.z, 0.0f);
+	}
+}
+
+// Additive blending into the RGBA32F target in frame order
+// (src/main.c:1000-1021, 1884-1888)
+__global__ void __launch_bounds__(PT_BLOCK) k_resolve(PtBatch batch, PtWavefront wf, f32x4* accum, int overwrite_first) {
+	uint32_t r = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (r >= batch.paths_per_frame)
+		return;
+	uint32_t x, y, frame_slot;
+	if (!pt_path_to_pixel(batch, r, &x, &y, &frame_slot))
+		return;
+	uint64_t pixel = (uint64_t) y * batch.width + x;
+	f32x4 sum = accum[pixel];
+	for (uint32_t f = 0; f != batch.frame_count; ++f) {
+		f32x4 radiance = wf.radiance[(uint64_t) f * batch.paths_per_frame + r];
+		if (f == 0 && overwrite_first)
+			sum = mk4(radiance.x, radiance.y, radiance.z, 1.0f);
+		else {
+			sum.x += radiance.x;
+			sum.y += radiance.y;
+			sum.z += radiance.z;
+		}
+	}
+	accum[pixel] = sum;
+}
+
+// Test hooks
+__global__ void __launch_bounds__(PT_BLOCK) k_gather_primary_hits(PtBatch batch, PtWavefront wf, int32_t* triangles, float* barycentrics, uint8_t* front) {
+	uint32_t p = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (p >= batch.paths_per_frame)
+		return;
+	uint32_t x, y, frame_slot;
+	if (!pt_path_to_pixel(batch, p, &x, &y, &frame_slot))
+		return;
+	uint64_t pixel = (uint64_t) y * batch.width + x;
+	u32x4 hit = wf.hit[p];
+	triangles[pixel] = (int32_t) hit.x;
+	barycentrics[2 * pixel] = pt_as_float(hit.y);
+	barycentrics[2 * pixel + 1] = pt_as_float(hit.z);
+	front[pixel] = (uint8_t) hit.w;
+}
+
+__global__ void __launch_bounds__(PT_BLOCK) k_trace_user_rays(PtTraceArgs a, const float* origins, const float* directions, uint32_t count, int32_t* triangles, float* t_u_v, uint8_t* front) {
+	__shared__ u32x2 lds_stack[PT_LDS_STACK * PT_BLOCK];
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i >= count)
+		return;
+	PtGpuStack stack;
+	stack.lds = &lds_stack[threadIdx.x];
+	stack.overflow = a.stack_overflow + i;
+	stack.overflow_stride = a.stack_overflow_stride;
+	stack.capacity = a.stack_capacity;
+	stack.sp = 0;
+	PtHit hit = pt_trace_closest<false>(a.scene.nodes, a.scene.tris, a.scene.triangle_count,
+		mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), mk3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]), 1.0e-3f, 1e38f, stack, NULL);
+	triangles[i] = (int32_t) hit.prim;
+	t_u_v[3 * i] = hit.t;
+	t_u_v[3 * i + 1] = hit.u;
+	t_u_v[3 * i + 2] = hit.v;
+	front[i] = hit.front ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(PT_BLOCK) k_shading_data(PtSceneView scene, const PtConstants* constants, const int32_t* triangles, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i >= count)
+		return;
+	PtShadingData s = pt_shading_data(scene, *constants, (uint32_t) triangles[i], barycentrics[2 * i], barycentrics[2 * i + 1], front[i] != 0, mk3(out_dirs[3 * i], out_dirs[3 * i + 1], out_dirs[3 * i + 2]));
+	float* o = &out[20 * (uint64_t) i];
+	o[0] = s.pos.x; o[1] = s.pos.y; o[2] = s.pos.z;
+	o[3] = s.normal.x; o[4] = s.normal.y; o[5] = s.normal.z;
+	o[6] = s.out_dir.x; o[7] = s.out_dir.y; o[8] = s.out_dir.z;
+	o[9] = s.lambert_out;
+	o[10] = s.emission.x; o[11] = s.emission.y; o[12] = s.emission.z;
+	o[13] = s.diffuse_albedo.x; o[14] = s.diffuse_albedo.y; o[15] = s.diffuse_albedo.z;
+	o[16] = s.fresnel_0.x; o[17] = s.fresnel_0.y; o[18] = s.fresnel_0.z;
+	o[19] = s.roughness;
+}
+
+__global__ void k_random_numbers(uint32_t x, uint32_t y, uint32_t frame_index, uint32_t draw_count, float* out) {
+	if (blockIdx.x != 0 || threadIdx.x != 0)
+		return;
+	uint32_t sx = x ^ (frame_index << 16), sy = y ^ ((frame_index + 237u) << 16);
+	for (uint32_t i = 0; i != draw_count; ++i) {
+		v2 r = pt_random(sx, sy);
+		out[2 * i] = r.x;
+		out[2 * i + 1] = r.y;
+	}
+}
+
+
+// ---------------------------------------------------------------- host side
+
+enum { PT_K_RAYGEN = 0, PT_K_TRACE_EXT = 1, PT_K_TRACE_SHADOW = 2, PT_K_SHADE = 3, PT_K_RESOLVE = 4, PT_K_COUNT = 5 };
+
+struct pt_scene {
+	int device;
+	hipStream_t stream;
+	// scene data
+	uint32_t triangle_count, material_count, texture_count;
+	u32x2* positions;
+	u32x2* normals_uvs;
+	uint8_t* materials;
+	PtTexture* textures;
+	uint8_t* texture_blob;
+	float* srgb_to_linear;
+	f32x4* lights;
+	uint32_t light_count;
+	PtNode* nodes;
+	PtTri* tris;
+	pt_bvh_info_t bvh_info;
+	// settings
+	int strategy;
+	uint32_t path_length, emission_material_index;
+	// render targets and wavefront buffers
+	uint32_t width, height;
+	PtBatch frame_layout; // tiles and paths per frame
+	uint32_t max_frames_per_batch;
+	uint32_t capacity; // paths per batch
+	f32x4* accum;
+	uint32_t sample_count;
+	PtWavefront wf;
+	uint32_t* counters; // ext_count[PT_MAX_PATH_LENGTH + 1], shadow_count[PT_MAX_PATH_LENGTH + 1]
+	PtConstants* constants;
+	u32x2* stack_overflow;
+	uint32_t stack_capacity, stack_overflow_stride;
+	unsigned long long* visit_counters;
+	// pinned host staging for counter readback
+	uint32_t* host_counters;
+	// instrumentation
+	int timing_enabled, visit_counters_enabled;
+	pt_statistics_t stats;
+	struct timed_launch { int kind; hipEvent_t begin, end; };
+	std::vector<timed_launch> pending_events;
+	std::vector<hipEvent_t> event_pool;
+	std::vector<uint32_t*> pending_counter_reads;
+};
+
+#define PT_COUNTER_WORDS (2 * (PT_MAX_PATH_LENGTH + 1))
+
+static uint32_t pt_grid(uint64_t count) { return (uint32_t) ((count + PT_BLOCK - 1) / PT_BLOCK); }
+// Grid for kernels that use pt_block_first_slot(): a multiple of 8 blocks
+static uint32_t pt_grid_chunked(uint64_t capacity) {
+	uint32_t blocks = pt_grid(capacity);
+	uint32_t chunk = (blocks + 7) / 8;
+	return chunk ? 8 * chunk : 8;
+}
+
+static PtSceneView pt_scene_view(const pt_scene* s) {
+	PtSceneView v;
+	v.nodes = s->nodes;
+	v.tris = s->tris;
+	v.triangle_count = s->triangle_count;
+	v.positions = s->positions;
+	v.normals_uvs = s->normals_uvs;
+	v.materials = s->materials;
+	v.textures = s->textures;
+	v.texture_blob = s->texture_blob;
+	v.srgb_to_linear = s->srgb_to_linear;
+	v.lights = s->lights;
+	v.light_count = s->light_count;
+	v.emission_material_index = s->emission_material_index;
+	return v;
+}
+
+static hipEvent_t pt_get_event(pt_scene* s) {
+	if (!s->event_pool.empty()) {
+		hipEvent_t e = s->event_pool.back();
+		s->event_pool.pop_back();
+		return e;
+	}
+	hipEvent_t e = NULL;
+	if (hipEventCreate(&e) != hipSuccess)
+		return NULL;
+	return e;
+}
+
+struct pt_launch_timer {
+	pt_scene* s;
+	int kind;
+	hipEvent_t begin, end;
+	pt_launch_timer(pt_scene* scene, int kind_) : s(scene), kind(kind_), begin(NULL), end(NULL) {
+		++s->stats.kernel_launches[kind];
+		if (s->timing_enabled) {
+			begin = pt_get_event(s);
+			end = pt_get_event(s);
+			if (begin && end)
+				hipEventRecord(begin, s->stream);
+		}
+	}
+	~pt_launch_timer() {
+		if (begin && end) {
+			hipEventRecord(end, s->stream);
+			pt_scene::timed_launch t = { kind, begin, end };
+			s->pending_events.push_back(t);
+		}
+	}
+};
+
+// Folds finished event pairs and counter snapshots into the statistics;
+// requires the stream to be idle
+static void pt_collect(pt_scene* s) {
+	for (size_t i = 0; i != s->pending_events.size(); ++i) {
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, s->pending_events[i].begin, s->pending_events[i].end) == hipSuccess)
+			s->stats.kernel_ms[s->pending_events[i].kind] += ms;
+		s->event_pool.push_back(s->pending_events[i].begin);
+		s->event_pool.push_back(s->pending_events[i].end);
+	}
+	s->pending_events.clear();
+	for (size_t i = 0; i != s->pending_counter_reads.size(); ++i) {
+		uint32_t* c = s->pending_counter_reads[i];
+		for (uint32_t k = 0; k <= PT_MAX_PATH_LENGTH; ++k) {
+			s->stats.extension_rays += c[k];
+			s->stats.shadow_rays += c[PT_MAX_PATH_LENGTH + 1 + k];
+		}
+		hipHostFree(c);
+	}
+	s->pending_counter_reads.clear();
+}
+
+template <typename T>
+static int pt_alloc(T** out, uint64_t count) {
+	*out = NULL;
+	PT_CHECK(hipMalloc((void**) out, (count ? count : 1) * sizeof(T)));
+	return 0;
+}
+
+static void pt_free_render_targets(pt_scene* s) {
+	hipFree(s->accum); s->accum = NULL;
+	for (int i = 0; i != 2; ++i) {
+		hipFree(s->wf.ray_o[i]); s->wf.ray_o[i] = NULL;
+		hipFree(s->wf.ray_d[i]); s->wf.ray_d[i] = NULL;
+	}
+	hipFree(s->wf.hit); s->wf.hit = NULL;
+	hipFree(s->wf.sh_o); s->wf.sh_o = NULL;
+	hipFree(s->wf.sh_d); s->wf.sh_d = NULL;
+	hipFree(s->wf.sh_w); s->wf.sh_w = NULL;
+	hipFree(s->wf.state0); s->wf.state0 = NULL;
+	hipFree(s->wf.state1); s->wf.state1 = NULL;
+	hipFree(s->wf.radiance); s->wf.radiance = NULL;
+	hipFree(s->stack_overflow); s->stack_overflow = NULL;
+	s->capacity = 0;
+	s->width = s->height = 0;
+}
+
+// Allocates wavefront buffers for at least path_count paths
+static int pt_reserve_wavefront(pt_scene* s, uint32_t path_count) {
+	if (path_count <= s->capacity)
+		return 0;
+	uint32_t w = s->width, h = s->height;
+	f32x4* accum = s->accum;
+	s->accum = NULL;
+	pt_free_render_targets(s);
+	s->accum = accum;
+	s->width = w;
+	s->height = h;
+	for (int i = 0; i != 2; ++i) {
+		if (pt_alloc(&s->wf.ray_o[i], path_count) || pt_alloc(&s->wf.ray_d[i], path_count))
+			return 1;
+	}
+	if (pt_alloc(&s->wf.hit, path_count) || pt_alloc(&s->wf.sh_o, path_count) || pt_alloc(&s->wf.sh_d, path_count) || pt_alloc(&s->wf.sh_w, path_count)
+		|| pt_alloc(&s->wf.state0, path_count) || pt_alloc(&s->wf.state1, path_count) || pt_alloc(&s->wf.radiance, path_count))
+		return 1;
+	s->stack_capacity = s->bvh_info.depth + 2;
+	if (s->stack_capacity < PT_LDS_STACK + 1)
+		s->stack_capacity = PT_LDS_STACK + 1;
+	s->stack_overflow_stride = pt_grid_chunked(path_count) * PT_BLOCK;
+	if (pt_alloc(&s->stack_overflow, (uint64_t) s->stack_overflow_stride * (s->stack_capacity - PT_LDS_STACK)))
+		return 1;
+	s->capacity = path_count;
+	return 0;
+}
+
+static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
+	uint32_t n = s->triangle_count;
+	hipEvent_t begin, end;
+	PT_CHECK(hipEventCreate(&begin));
+	PT_CHECK(hipEventCreate(&end));
+	PT_CHECK(hipEventRecord(begin, s->stream));
+	PtBuild b;
+	memset(&b, 0, sizeof(b));
+	b.n = n;
+	b.positions = s->positions;
+	memcpy(b.factor, header->dequantization_factor, sizeof(b.factor));
+	memcpy(b.summand, header->dequantization_summand, sizeof(b.summand));
+	uint64_t* keys_sorted = NULL;
+	uint32_t* order_sorted = NULL;
+	void* sort_temp = NULL;
+	int result = 1;
+	// The wide BVH has at most one node per two leaf groups; n nodes is a safe bound
+	uint32_t max_nodes = n ? n : 1;
+	do {
+		if (pt_alloc(&s->nodes, max_nodes) || pt_alloc(&s->tris, n))
+			break;
+		if (n == 0) {
+			PtNode empty;
+			memset(&empty, 0, sizeof(empty));
+			if (hipMemcpyAsync(s->nodes, &empty, sizeof(empty), hipMemcpyHostToDevice, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess)
+				break;
+			s->bvh_info.node_count = 1;
+			s->bvh_info.depth = 1;
+			result = 0;
+			break;
+		}
+		if (pt_alloc(&b.verts, 9 * (uint64_t) n) || pt_alloc(&b.bounds, 6) || pt_alloc(&b.keys, n) || pt_alloc(&b.order, n)
+			|| pt_alloc(&keys_sorted, n) || pt_alloc(&order_sorted, n)
+			|| pt_alloc(&b.left, n) || pt_alloc(&b.right, n) || pt_alloc(&b.parent, 2 * (uint64_t) n)
+			|| pt_alloc(&b.range_first, n) || pt_alloc(&b.range_last, n) || pt_alloc(&b.box, 12 * (uint64_t) n)
+			|| pt_alloc(&b.flags, n) || pt_alloc(&b.task_binary, max_nodes) || pt_alloc(&b.counters, 2))
+			break;
+		b.nodes = s->nodes;
+		b.tris = s->tris;
+		uint32_t bounds_init[6] = { 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u };
+		uint32_t counters_init[2] = { 1u, 0u };
+		uint32_t root_task = 0;
+		if (hipMemcpyAsync(b.bounds, bounds_init, sizeof(bounds_init), hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(b.counters, counters_init, sizeof(counters_init), hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(b.task_binary, &root_task, sizeof(root_task), hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * n, s->stream) != hipSuccess)
+			break;
+		hipLaunchKernelGGL(k_build_dequantize, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+		hipLaunchKernelGGL(k_build_morton, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+		size_t temp_bytes = 0;
+		if (rocprim::radix_sort_pairs(NULL, temp_bytes, b.keys, keys_sorted, b.order, order_sorted, n, 0, 63, s->stream) != hipSuccess)
+			break;
+		if (hipMalloc(&sort_temp, temp_bytes ? temp_bytes : 1) != hipSuccess)
+			break;
+		if (rocprim::radix_sort_pairs(sort_temp, temp_bytes, b.keys, keys_sorted, b.order, order_sorted, n, 0, 63, s->stream) != hipSuccess)
+			break;
+		{ uint64_t* t = b.keys; b.keys = keys_sorted; keys_sorted = t; }
+		{ uint32_t* t = b.order; b.order = order_sorted; order_sorted = t; }
+		if (n > 1)
+			hipLaunchKernelGGL(k_build_radix_tree, dim3(pt_grid(n - 1)), dim3(PT_BLOCK), 0, s->stream, b);
+		hipLaunchKernelGGL(k_build_refit, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+		// Collapse level by level: the nodes allocated while processing one
+		// level form the next level
+		uint32_t level_begin = 0, level_end = 1, depth = 0;
+		bool failed = false;
+		while (level_begin < level_end) {
+			hipLaunchKernelGGL(k_build_collapse, dim3(pt_grid(level_end - level_begin)), dim3(PT_BLOCK), 0, s->stream, b, level_begin, level_end);
+			uint32_t counters[2];
+			if (hipMemcpyAsync(counters, b.counters, sizeof(counters), hipMemcpyDeviceToHost, s->stream) != hipSuccess || hipStreamSynchronize(s->stream) != hipSuccess) {
+				failed = true;
+				break;
+			}
+			if (counters[0] > max_nodes || counters[1] > n) {
+				printf("BVH collapse overran its buffers (%u nodes, %u triangles).\n", counters[0], counters[1]);
+				failed = true;
+				break;
+			}
+			level_begin = level_end;
+			level_end = counters[0];
+			++depth;
+			s->bvh_info.triangle_count = counters[1];
+		}
+		if (failed || hipGetLastError() != hipSuccess)
+			break;
+		s->bvh_info.node_count = level_end;
+		s->bvh_info.depth = depth;
+		result = 0;
+	} while (0);
+	hipEventRecord(end, s->stream);
+	hipStreamSynchronize(s->stream);
+	hipEventElapsedTime(&s->bvh_info.build_ms, begin, end);
+	hipEventDestroy(begin);
+	hipEventDestroy(end);
+	hipFree(b.verts); hipFree(b.bounds); hipFree(b.keys); hipFree(b.order); hipFree(keys_sorted); hipFree(order_sorted);
+	hipFree(b.left); hipFree(b.right); hipFree(b.parent); hipFree(b.range_first); hipFree(b.range_last); hipFree(b.box);
+	hipFree(b.flags); hipFree(b.task_binary); hipFree(b.counters); hipFree(sort_temp);
+	s->bvh_info.node_bytes = sizeof(PtNode);
+	s->bvh_info.triangle_bytes = sizeof(PtTri);
+	if (result)
+		printf("Failed to build the BVH for %u triangles on the GPU.\n", n);
+	return result;
+}
+
+extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const pt_scene_header_t* header,
+	const uint32_t* positions, const uint16_t* normals_and_tex_coords, const uint8_t* material_indices,
+	const pt_texture_desc_t* textures, uint32_t texture_count)
+{
+	if (!out_scene)
+		return 1;
+	*out_scene = NULL;
+	if (!header || (header->triangle_count && (!positions || !normals_and_tex_coords || !material_indices))) {
+		printf("pt_create_scene() needs a header and all three mesh arrays.\n");
+		return 1;
+	}
+	if (header->triangle_count > 0x55555555ull) {
+		printf("pt_create_scene() supports at most %u triangles, got %llu.\n", 0x55555555u, (unsigned long long) header->triangle_count);
+		return 1;
+	}
+	if (texture_count != 3 * header->material_count || (texture_count && !textures)) {
+		printf("pt_create_scene() needs three textures per material (%llu materials, %u textures).\n", (unsigned long long) header->material_count, texture_count);
+		return 1;
+	}
+	for (uint32_t i = 0; i != texture_count; ++i) {
+		const pt_texture_desc_t* t = &textures[i];
+		bool pow2 = t->width >= 4 && t->height >= 4 && !(t->width & (t->width - 1)) && !(t->height & (t->height - 1));
+		if ((t->format != 131 && t->format != 132 && t->format != 141) || !pow2 || t->mip_count < 1 || t->mip_count > PT_MAX_MIPS || !t->mip_data || !t->mip_sizes) {
+			printf("Texture %u is not supported (format %u, %ux%u, %u mipmaps).\n", i, t->format, t->width, t->height, t->mip_count);
+			return 1;
+		}
+		uint64_t expected = (uint64_t) ((t->width + 3) / 4) * ((t->height + 3) / 4) * ((t->format == 141) ? 16 : 8);
+		if (t->mip_sizes[0] != expected || !t->mip_data[0]) {
+			printf("The data block for mipmap 0 of texture %u was supposed to have %llu bytes but had %llu bytes.\n", i, (unsigned long long) expected, (unsigned long long) t->mip_sizes[0]);
+			return 1;
+		}
+	}
+	if (hipSetDevice(device_index) != hipSuccess) {
+		printf("Failed to select GPU %d.\n", device_index);
+		return 1;
+	}
+	pt_scene* s = new pt_scene();
+	s->device = device_index;
+	s->stream = NULL;
+	s->triangle_count = (uint32_t) header->triangle_count;
+	s->material_count = (uint32_t) header->material_count;
+	s->texture_count = texture_count;
+	s->positions = NULL; s->normals_uvs = NULL; s->materials = NULL; s->textures = NULL; s->texture_blob = NULL;
+	s->srgb_to_linear = NULL; s->lights = NULL; s->light_count = 0; s->nodes = NULL; s->tris = NULL;
+	memset(&s->bvh_info, 0, sizeof(s->bvh_info));
+	s->strategy = PT_STRATEGY_NEE;
+	s->path_length = 4;
+	s->emission_material_index = 0;
+	s->width = s->height = 0;
+	memset(&s->frame_layout, 0, sizeof(s->frame_layout));
+	s->max_frames_per_batch = 0;
+	s->capacity = 0;
+	s->accum = NULL;
+	s->sample_count = 0;
+	memset(&s->wf, 0, sizeof(s->wf));
+	s->counters = NULL; s->constants = NULL; s->stack_overflow = NULL; s->visit_counters = NULL; s->host_counters = NULL;
+	s->stack_capacity = s->stack_overflow_stride = 0;
+	s->timing_enabled = s->visit_counters_enabled = 0;
+	memset(&s->stats, 0, sizeof(s->stats));
+	int failed = 1;
+	do {
+		if (hipStreamCreate(&s->stream) != hipSuccess)
+			break;
+		uint64_t n = s->triangle_count;
+		if (pt_alloc(&s->positions, 3 * n) || pt_alloc(&s->normals_uvs, 3 * n) || pt_alloc(&s->materials, n)
+			|| pt_alloc(&s->counters, PT_COUNTER_WORDS) || pt_alloc(&s->constants, 1) || pt_alloc(&s->visit_counters, 4)
+			|| pt_alloc(&s->srgb_to_linear, 256) || pt_alloc(&s->lights, 1))
+			break;
+		if (n) {
+			if (hipMemcpyAsync(s->positions, positions, n * 24, hipMemcpyHostToDevice, s->stream) != hipSuccess
+				|| hipMemcpyAsync(s->normals_uvs, normals_and_tex_coords, n * 24, hipMemcpyHostToDevice, s->stream) != hipSuccess
+				|| hipMemcpyAsync(s->materials, material_indices, n, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+				break;
+		}
+		if (hipMemsetAsync(s->visit_counters, 0, 4 * sizeof(unsigned long long), s->stream) != hipSuccess)
+			break;
+		// sRGB decoding table for VK_FORMAT_BC1_RGB_SRGB_BLOCK textures
+		float table[256];
+		for (int i = 0; i != 256; ++i) {
+			double c = i / 255.0;
+			table[i] = (float) ((c <= 0.04045) ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+		}
+		if (hipMemcpyAsync(s->srgb_to_linear, table, sizeof(table), hipMemcpyHostToDevice, s->stream) != hipSuccess)
+			break;
+		// Pack all mip payloads into one blob, each on a 16-byte boundary
+		std::vector<PtTexture> descs(texture_count ? texture_count : 1);
+		uint64_t blob_size = 0;
+		for (uint32_t i = 0; i != texture_count; ++i) {
+			descs[i].width = textures[i].width;
+			descs[i].height = textures[i].height;
+			descs[i].format = textures[i].format;
+			descs[i].mip_count = textures[i].mip_count;
+			for (uint32_t m = 0; m != textures[i].mip_count; ++m) {
+				descs[i].mip_offsets[m] = blob_size;
+				blob_size += (textures[i].mip_sizes[m] + 15) & ~15ull;
+			}
+		}
+		std::vector<uint8_t> blob(blob_size ? blob_size : 16);
+		for (uint32_t i = 0; i != texture_count; ++i)
+			for (uint32_t m = 0; m != textures[i].mip_count; ++m)
+				if (textures[i].mip_data[m])
+					memcpy(&blob[descs[i].mip_offsets[m]], textures[i].mip_data[m], textures[i].mip_sizes[m]);
+		if (pt_alloc(&s->texture_blob, blob.size()) || pt_alloc(&s->textures, descs.size()))
+			break;
+		if (hipMemcpyAsync(s->texture_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(s->textures, descs.data(), descs.size() * sizeof(PtTexture), hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipStreamSynchronize(s->stream) != hipSuccess)
+			break;
+		if (pt_build_bvh(s, header))
+			break;
+		failed = 0;
+	} while (0);
+	if (failed) {
+		printf("Failed to create the scene on GPU %d.\n", device_index);
+		pt_destroy_scene(s);
+		return 1;
+	}
+	*out_scene = s;
+	return 0;
+}
+
+extern "C" void pt_destroy_scene(pt_scene_t* s) {
+	if (!s)
+		return;
+	hipSetDevice(s->device);
+	if (s->stream)
+		hipStreamSynchronize(s->stream);
+	pt_collect(s);
+	for (size_t i = 0; i != s->event_pool.size(); ++i)
+		hipEventDestroy(s->event_pool[i]);
+	pt_free_render_targets(s);
+	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->materials); hipFree(s->textures); hipFree(s->texture_blob);
+	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->nodes); hipFree(s->tris);
+	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters);
+	if (s->stream)
+		hipStreamDestroy(s->stream);
+	delete s;
+}
+
+extern "C" int pt_set_lights(pt_scene_t* s, const float* lights, uint32_t count) {
+	if (!s || (count && !lights))
+		return 1;
+	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(hipStreamSynchronize(s->stream));
+	f32x4* fresh = NULL;
+	if (pt_alloc(&fresh, count))
+		return 1;
+	if (count)
+		PT_CHECK(hipMemcpy(fresh, lights, sizeof(float) * 4 * count, hipMemcpyHostToDevice));
+	hipFree(s->lights);
+	s->lights = fresh;
+	s->light_count = count;
+	return 0;
+}
+
+extern "C" int pt_set_render_settings(pt_scene_t* s, int sampling_strategy, uint32_t path_length, uint32_t emission_material_index) {
+	if (!s)
+		return 1;
+	if (sampling_strategy < 0 || sampling_strategy > 3 || path_length > PT_MAX_PATH_LENGTH) {
+		printf("Unsupported render settings: sampling strategy %d, path length %u.\n", sampling_strategy, path_length);
+		return 1;
+	}
+	s->strategy = sampling_strategy;
+	s->path_length = path_length;
+	s->emission_material_index = emission_material_index;
+	return 0;
+}
+
+extern "C" int pt_create_render_targets(pt_scene_t* s, uint32_t width, uint32_t height) {
+	if (!s)
+		return 1;
+	if (width == 0 || height == 0 || (uint64_t) width * height > (1ull << 28)) {
+		printf("Unsupported render target extent %ux%u.\n", width, height);
+		return 1;
+	}
+	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(hipStreamSynchronize(s->stream));
+	pt_collect(s);
+	pt_free_render_targets(s);
+	s->width = width;
+	s->height = height;
+	PtBatch& l = s->frame_layout;
+	l.width = width;
+	l.height = height;
+	l.tiles_x = (width + PT_TILE - 1) / PT_TILE;
+	l.tiles_y = (height + PT_TILE - 1) / PT_TILE;
+	l.paths_per_frame = l.tiles_x * l.tiles_y * 64;
+	// Enough paths per batch to fill the chip several times over
+	const uint64_t target_paths = 4ull << 20;
+	s->max_frames_per_batch = (uint32_t) ((target_paths + l.paths_per_frame - 1) / l.paths_per_frame);
+	if (s->max_frames_per_batch < 1) s->max_frames_per_batch = 1;
+	if (s->max_frames_per_batch > 64) s->max_frames_per_batch = 64;
+	if (pt_alloc(&s->accum, (uint64_t) width * height)) {
+		pt_free_render_targets(s);
+		return 1;
+	}
+	PT_CHECK(hipMemsetAsync(s->accum, 0, sizeof(f32x4) * (uint64_t) width * height, s->stream));
+	s->sample_count = 0;
+	return 0;
+}
+
+static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity) {
+	PtTraceArgs a;
+	a.scene = pt_scene_view(s);
+	a.wf = s->wf;
+	a.constants = s->constants;
+	a.stack_overflow = s->stack_overflow;
+	a.stack_overflow_stride = s->stack_overflow_stride;
+	a.stack_capacity = s->stack_capacity;
+	a.bounce = bounce;
+	a.parity = parity;
+	a.visit_counters = s->visit_counters_enabled ? s->visit_counters : NULL;
+	return a;
+}
+
+static void pt_launch_trace_extension(pt_scene* s, uint32_t bounce, uint32_t parity, uint32_t capacity) {
+	pt_launch_timer timer(s, PT_K_TRACE_EXT);
+	PtTraceArgs a = pt_trace_args(s, bounce, parity);
+	if (s->visit_counters_enabled)
+		hipLaunchKernelGGL(k_trace_extension<true>, dim3(pt_grid_chunked(capacity)), dim3(PT_BLOCK), 0, s->stream, a);
+	else
+		hipLaunchKernelGGL(k_trace_extension<false>, dim3(pt_grid_chunked(capacity)), dim3(PT_BLOCK), 0, s->stream, a);
+}
+
+// Renders one batch of frame_count frames
+static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t frame_count, uint32_t frame_stride, int overwrite_first) {
+	PtBatch batch = s->frame_layout;
+	batch.frame_count = frame_count;
+	batch.first_frame_index = first_frame_index;
+	batch.frame_stride = frame_stride;
+	uint32_t path_count = batch.paths_per_frame * frame_count;
+	s->wf.ext_count = s->counters;
+	s->wf.shadow_count = s->counters + PT_MAX_PATH_LENGTH + 1;
+	PT_CHECK(hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * PT_COUNTER_WORDS, s->stream));
+	{
+		pt_launch_timer timer(s, PT_K_RAYGEN);
+		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count);
+	}
+	uint32_t parity = 0;
+	for (uint32_t k = 1; k <= s->path_length; ++k) {
+		pt_launch_trace_extension(s, k - 1, parity, path_count);
+		{
+			pt_launch_timer timer(s, PT_K_SHADE);
+			PtShadeArgs a;
+			a.scene = pt_scene_view(s);
+			a.wf = s->wf;
+			a.constants = s->constants;
+			a.strategy = s->strategy;
+			a.path_length = s->path_length;
+			a.k = k;
+			a.parity = parity;
+			a.visit_counters = s->visit_counters_enabled ? s->visit_counters : NULL;
+			hipLaunchKernelGGL(k_shade, dim3(pt_grid_chunked(path_count)), dim3(PT_BLOCK), 0, s->stream, a);
+		}
+		if (s->strategy == PT_STRATEGY_NEE && k < s->path_length) {
+			pt_launch_timer timer(s, PT_K_TRACE_SHADOW);
+			PtTraceArgs a = pt_trace_args(s, k, 0);
+			if (s->visit_counters_enabled)
+				hipLaunchKernelGGL(k_trace_shadow<true>, dim3(pt_grid_chunked(path_count)), dim3(PT_BLOCK), 0, s->stream, a);
+			else
+				hipLaunchKernelGGL(k_trace_shadow<false>, dim3(pt_grid_chunked(path_count)), dim3(PT_BLOCK), 0, s->stream, a);
+		}
+		parity ^= 1;
+	}
+	{
+		pt_launch_timer timer(s, PT_K_RESOLVE);
+		hipLaunchKernelGGL(k_resolve, dim3(pt_grid(batch.paths_per_frame)), dim3(PT_BLOCK), 0, s->stream, batch, s->wf, s->accum, overwrite_first);
+	}
+	// Snapshot the queue sizes of this batch for the ray statistics
+	uint32_t* snapshot = NULL;
+	PT_CHECK(hipHostMalloc((void**) &snapshot, sizeof(uint32_t) * PT_COUNTER_WORDS, hipHostMallocDefault));
+	PT_CHECK(hipMemcpyAsync(snapshot, s->counters, sizeof(uint32_t) * PT_COUNTER_WORDS, hipMemcpyDeviceToHost, s->stream));
+	s->pending_counter_reads.push_back(snapshot);
+	s->stats.paths += (uint64_t) s->width * s->height * frame_count;
+	PT_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int pt_render_samples(pt_scene_t* s, const pt_constants_t* constants,
+	uint32_t first_frame_index, uint32_t sample_count, uint32_t frame_stride, int accumulate)
+{
+	if (!s || !constants)
+		return 1;
+	if (!s->accum) {
+		printf("pt_render_samples() needs render targets; call pt_create_render_targets() first.\n");
+		return 1;
+	}
+	if ((uint32_t) constants->viewport_size[0] != s->width || (uint32_t) constants->viewport_size[1] != s->height) {
+		printf("The viewport size %gx%g in the constants does not match the %ux%u render targets.\n", constants->viewport_size[0], constants->viewport_size[1], s->width, s->height);
+		return 1;
+	}
+	if (sample_count == 0)
+		return 0;
+	PT_CHECK(hipSetDevice(s->device));
+	uint32_t frames_per_batch = s->max_frames_per_batch < sample_count ? s->max_frames_per_batch : sample_count;
+	if (pt_reserve_wavefront(s, s->frame_layout.paths_per_frame * frames_per_batch))
+		return 1;
+	// Keep the backlog of events and snapshots bounded
+	if (s->pending_counter_reads.size() > 256) {
+		PT_CHECK(hipStreamSynchronize(s->stream));
+		pt_collect(s);
+	}
+	PT_CHECK(hipMemcpyAsync(s->constants, constants, sizeof(PtConstants), hipMemcpyHostToDevice, s->stream));
+	if (!accumulate)
+		s->sample_count = 0;
+	uint32_t done = 0;
+	while (done < sample_count) {
+		uint32_t frames = sample_count - done;
+		if (frames > frames_per_batch)
+			frames = frames_per_batch;
+		int overwrite_first = (!accumulate && done == 0) ? 1 : 0;
+		if (pt_render_batch(s, first_frame_index + done * frame_stride, frames, frame_stride, overwrite_first))
+			return 1;
+		done += frames;
+	}
+	s->sample_count += sample_count;
+	return 0;
+}
+
+extern "C" int pt_synchronize(pt_scene_t* s) {
+	if (!s)
+		return 1;
+	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(hipStreamSynchronize(s->stream));
+	pt_collect(s);
+	return 0;
+}
+
+extern "C" int pt_read_accumulation(pt_scene_t* s, float* rgba, uint32_t* out_sample_count) {
+	if (!s)
+		return 1;
+	if (pt_synchronize(s))
+		return 1;
+	if (rgba) {
+		if (!s->accum) {
+			printf("There are no render targets to read.\n");
+			return 1;
+		}
+		PT_CHECK(hipMemcpy(rgba, s->accum, sizeof(f32x4) * (uint64_t) s->width * s->height, hipMemcpyDeviceToHost));
+	}
+	if (out_sample_count)
+		*out_sample_count = s->sample_count;
+	return 0;
+}
+
+extern "C" void* pt_get_accumulation_device_pointer(pt_scene_t* s) { return s ? (void*) s->accum : NULL; }
+
+extern "C" int pt_set_sample_count(pt_scene_t* s, uint32_t sample_count) {
+	if (!s)
+		return 1;
+	s->sample_count = sample_count;
+	return 0;
+}
+
+extern "C" int pt_set_instrumentation(pt_scene_t* s, int enable_kernel_timing, int enable_visit_counters) {
+	if (!s)
+		return 1;
+	if (pt_synchronize(s))
+		return 1;
+	s->timing_enabled = enable_kernel_timing;
+	s->visit_counters_enabled = enable_visit_counters;
+	return 0;
+}
+
+extern "C" int pt_get_statistics(pt_scene_t* s, pt_statistics_t* out) {
+	if (!s || !out)
+		return 1;
+	if (pt_synchronize(s))
+		return 1;
+	unsigned long long visits[4] = { 0, 0, 0, 0 };
+	PT_CHECK(hipMemcpy(visits, s->visit_counters, sizeof(visits), hipMemcpyDeviceToHost));
+	s->stats.nodes_visited = visits[0];
+	s->stats.triangles_tested = visits[1];
+	s->stats.shaded_hits = visits[2];
+	*out = s->stats;
+	return 0;
+}
+
+extern "C" int pt_reset_statistics(pt_scene_t* s) {
+	if (!s)
+		return 1;
+	if (pt_synchronize(s))
+		return 1;
+	memset(&s->stats, 0, sizeof(s->stats));
+	PT_CHECK(hipMemset(s->visit_counters, 0, 4 * sizeof(unsigned long long)));
+	return 0;
+}
+
+extern "C" int pt_get_bvh_info(pt_scene_t* s, pt_bvh_info_t* out) {
+	if (!s || !out)
+		return 1;
+	*out = s->bvh_info;
+	return 0;
+}
+
+extern "C" int pt_trace_primary_rays(pt_scene_t* s, const pt_constants_t* constants, uint32_t frame_index,
+	int32_t* triangle_indices, float* barycentrics, uint8_t* front)
+{
+	if (!s || !constants || !triangle_indices || !barycentrics || !front)
+		return 1;
+	if (!s->accum || (uint32_t) constants->viewport_size[0] != s->width || (uint32_t) constants->viewport_size[1] != s->height) {
+		printf("pt_trace_primary_rays() needs render targets matching the viewport size in the constants.\n");
+		return 1;
+	}
+	PT_CHECK(hipSetDevice(s->device));
+	if (pt_reserve_wavefront(s, s->frame_layout.paths_per_frame))
+		return 1;
+	PtBatch batch = s->frame_layout;
+	batch.frame_count = 1;
+	batch.first_frame_index = frame_index;
+	batch.frame_stride = 1;
+	uint32_t path_count = batch.paths_per_frame;
+	uint64_t pixels = (uint64_t) s->width * s->height;
+	int32_t* d_triangles = NULL;
+	float* d_barycentrics = NULL;
+	uint8_t* d_front = NULL;
+	int result = 1;
+	do {
+		if (pt_alloc(&d_triangles, pixels) || pt_alloc(&d_barycentrics, 2 * pixels) || pt_alloc(&d_front, pixels))
+			break;
+		s->wf.ext_count = s->counters;
+		s->wf.shadow_count = s->counters + PT_MAX_PATH_LENGTH + 1;
+		if (hipMemcpyAsync(s->constants, constants, sizeof(PtConstants), hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * PT_COUNTER_WORDS, s->stream) != hipSuccess)
+			break;
+		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count);
+		PtTraceArgs a = pt_trace_args(s, 0, 0);
+		hipLaunchKernelGGL(k_trace_extension<false>, dim3(pt_grid_chunked(path_count)), dim3(PT_BLOCK), 0, s->stream, a);
+		hipLaunchKernelGGL(k_gather_primary_hits, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->wf, d_triangles, d_barycentrics, d_front);
+		if (hipMemcpyAsync(triangle_indices, d_triangles, pixels * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess
+			|| hipMemcpyAsync(barycentrics, d_barycentrics, 2 * pixels * sizeof(float), hipMemcpyDeviceToHost, s->stream) != hipSuccess
+			|| hipMemcpyAsync(front, d_front, pixels, hipMemcpyDeviceToHost, s->stream) != hipSuccess
+			|| hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+			break;
+		result = 0;
+	} while (0);
+	hipFree(d_triangles); hipFree(d_barycentrics); hipFree(d_front);
+	if (result)
+		printf("Failed to trace primary rays on the GPU.\n");
+	return result;
+}
+
+extern "C" int pt_trace_rays(pt_scene_t* s, const float* origins, const float* directions, uint32_t ray_count,
+	int32_t* triangle_indices, float* t_u_v, uint8_t* front)
+{
+	if (!s || (ray_count && (!origins || !directions || !triangle_indices || !t_u_v || !front)))
+		return 1;
+	if (ray_count == 0)
+		return 0;
+	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(hipStreamSynchronize(s->stream));
+	float* d_origins = NULL; float* d_directions = NULL; int32_t* d_triangles = NULL; float* d_tuv = NULL; uint8_t* d_front = NULL;
+	u32x2* overflow = NULL;
+	int result = 1;
+	do {
+		uint32_t stack_capacity = s->bvh_info.depth + 2;
+		if (stack_capacity < PT_LDS_STACK + 1) stack_capacity = PT_LDS_STACK + 1;
+		uint32_t stride = pt_grid(ray_count) * PT_BLOCK;
+		if (pt_alloc(&d_origins, 3 * (uint64_t) ray_count) || pt_alloc(&d_directions, 3 * (uint64_t) ray_count) || pt_alloc(&d_triangles, ray_count)
+			|| pt_alloc(&d_tuv, 3 * (uint64_t) ray_count) || pt_alloc(&d_front, ray_count) || pt_alloc(&overflow, (uint64_t) stride * (stack_capacity - PT_LDS_STACK)))
+			break;
+		if (hipMemcpyAsync(d_origins, origins, sizeof(float) * 3 * ray_count, hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(d_directions, directions, sizeof(float) * 3 * ray_count, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+			break;
+		PtTraceArgs a = pt_trace_args(s, 0, 0);
+		a.stack_overflow = overflow;
+		a.stack_overflow_stride = stride;
+		a.stack_capacity = stack_capacity;
+		hipLaunchKernelGGL(k_trace_user_rays, dim3(pt_grid(ray_count)), dim3(PT_BLOCK), 0, s->stream, a, d_origins, d_directions, ray_count, d_triangles, d_tuv, d_front);
+		if (hipMemcpyAsync(triangle_indices, d_triangles, sizeof(int32_t) * ray_count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
+			|| hipMemcpyAsync(t_u_v, d_tuv, sizeof(float) * 3 * ray_count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
+			|| hipMemcpyAsync(front, d_front, ray_count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
+			|| hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+			break;
+		result = 0;
+	} while (0);
+	hipFree(d_origins); hipFree(d_directions); hipFree(d_triangles); hipFree(d_tuv); hipFree(d_front); hipFree(overflow);
+	if (result)
+		printf("Failed to trace %u rays on the GPU.\n", ray_count);
+	return result;
+}
+
+extern "C" int pt_evaluate_shading_data(pt_scene_t* s, const pt_constants_t* constants,
+	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs,
+	uint32_t count, float* out_shading_data)
+{
+	if (!s || !constants || (count && (!triangle_indices || !barycentrics || !front || !out_dirs || !out_shading_data)))
+		return 1;
+	if (count == 0)
+		return 0;
+	for (uint32_t i = 0; i != count; ++i) {
+		if (triangle_indices[i] < 0 || (uint32_t) triangle_indices[i] >= s->triangle_count) {
+			printf("Triangle index %d of hit %u is out of range.\n", triangle_indices[i], i);
+			return 1;
+		}
+	}
+	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(hipStreamSynchronize(s->stream));
+	int32_t* d_triangles = NULL; float* d_barycentrics = NULL; uint8_t* d_front = NULL; float* d_dirs = NULL; float* d_out = NULL;
+	int result = 1;
+	do {
+		if (pt_alloc(&d_triangles, count) || pt_alloc(&d_barycentrics, 2 * (uint64_t) count) || pt_alloc(&d_front, count) || pt_alloc(&d_dirs, 3 * (uint64_t) count) || pt_alloc(&d_out, 20 * (uint64_t) count))
+			break;
+		if (hipMemcpyAsync(s->constants, constants, sizeof(PtConstants), hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(d_triangles, triangle_indices, sizeof(int32_t) * count, hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(d_barycentrics, barycentrics, sizeof(float) * 2 * count, hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(d_front, front, count, hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(d_dirs, out_dirs, sizeof(float) * 3 * count, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+			break;
+		hipLaunchKernelGGL(k_shading_data, dim3(pt_grid(count)), dim3(PT_BLOCK), 0, s->stream, pt_scene_view(s), s->constants, d_triangles, d_barycentrics, d_front, d_dirs, count, d_out);
+		if (hipMemcpyAsync(out_shading_data, d_out, sizeof(float) * 20 * count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
+			|| hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+			break;
+		result = 0;
+	} while (0);
+	hipFree(d_triangles); hipFree(d_barycentrics); hipFree(d_front); hipFree(d_dirs); hipFree(d_out);
+	if (result)
+		printf("Failed to evaluate shading data on the GPU.\n");
+	return result;
+}
+
+extern "C" int pt_random_numbers(int device_index, uint32_t x, uint32_t y, uint32_t frame_index, uint32_t draw_count, float* out_randoms) {
+	if (!out_randoms && draw_count)
+		return 1;
+	if (draw_count == 0)
+		return 0;
+	PT_CHECK(hipSetDevice(device_index));
+	float* d_out = NULL;
+	if (pt_alloc(&d_out, 2 * (uint64_t) draw_count))
+		return 1;
+	hipLaunchKernelGGL(k_random_numbers, dim3(1), dim3(64), 0, 0, x, y, frame_index, draw_count, d_out);
+	hipError_t err = hipMemcpy(out_randoms, d_out, sizeof(float) * 2 * draw_count, hipMemcpyDeviceToHost);
+	hipFree(d_out);
+	if (err != hipSuccess || hipGetLastError() != hipSuccess) {
+		printf("Failed to generate random numbers on the GPU.\n");
+		return 1;
+	}
+	return 0;
+}

@@ -1,0 +1,529 @@
+// Per-path-vertex work of the wavefront path tracer: random numbers, camera
+// rays, mesh and texture decode, the Frostbite BRDF with its samplers, and
+// spherical-light sampling. Each function states the lines of the reference
+// shader it implements (paths relative to src/shaders/).
+#pragma once
+#include "pt_common.h"
+
+// ---- pathtrace.frag.glsl:23-34, PCG2D ----
+PT_FN v2 pt_random(uint32_t& sx, uint32_t& sy) {
+	sx = 1664525u * sx + 1013904223u;
+	sy = 1664525u * sy + 1013904223u;
+	sx += 1664525u * sy;
+	sy += 1664525u * sx;
+	sx ^= sx >> 16;
+	sy ^= sy >> 16;
+	sx += 1664525u * sy;
+	sy += 1664525u * sx;
+	sx ^= sx >> 16;
+	sy ^= sy >> 16;
+	return mk2((float) sx * 2.32830643654e-10f, (float) sy * 2.32830643654e-10f);
+}
+
+// ---- pathtrace.frag.glsl:38-45 ----
+PT_FN float pt_erfinv(float x) {
+	float w = -pt_log(fmaxf(1.0e-37f, 1.0f - x * x));
+	float a = w - 2.5f;
+	float b = sqrtf(w) - 3.0f;
+	float pa = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(2.81022636e-08f, a, 3.43273939e-07f), a, -3.5233877e-06f), a, -4.39150654e-06f), a, 0.00021858087f), a, -0.00125372503f), a, -0.00417768164f), a, 0.246640727f), a, 1.50140941f);
+	float pb = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(-0.000200214257f, b, 0.000100950558f), b, 0.00134934322f), b, -0.00367342844f), b, 0.00573950773f), b, -0.0076224613f), b, 0.00943887047f), b, 1.00167406f), b, 2.83297682f);
+	return x * ((w < 5.0f) ? pa : pb);
+}
+
+struct PtFrame { v3 b1, b2, n; };
+
+// ---- brdfs.glsl:126-134 ----
+PT_FN PtFrame pt_shading_space(v3 n) {
+	float s = (n.z > 0.0f) ? 1.0f : -1.0f;
+	float a = -1.0f / (s + n.z);
+	float b = n.x * n.y * a;
+	PtFrame f;
+	f.b1 = mk3(1.0f + s * n.x * n.x * a, s * b, -s * n.x);
+	f.b2 = mk3(b, s + n.y * n.y * a, -n.y);
+	f.n = n;
+	return f;
+}
+PT_FN v3 pt_to_world(const PtFrame& f, v3 v) { return (f.b1 * v.x + f.b2 * v.y) + f.n * v.z; }
+PT_FN v3 pt_to_local(const PtFrame& f, v3 v) { return mk3(dot(f.b1, v), dot(f.b2, v), dot(f.n, v)); }
+
+// ---- pathtrace.frag.glsl:50-55 ----
+PT_FN v3 pt_sample_hemisphere_spherical(v2 randoms) {
+	float azimuth = (2.0f * PT_PI) * randoms.x - PT_PI;
+	float inclination = (0.5f * PT_PI) * randoms.y;
+	float si, ci, sa, ca;
+	pt_sincos(inclination, &si, &ci);
+	pt_sincos(azimuth, &sa, &ca);
+	return mk3(si * ca, si * sa, ci);
+}
+
+// ---- pathtrace.frag.glsl:60-64 ----
+PT_FN float pt_hemisphere_spherical_density(float z) {
+	if (z < 0.0f)
+		return 0.0f;
+	return 1.0f / ((PT_PI * PT_PI) * sqrtf(fmaxf(0.0f, 1.0f - z * z)));
+}
+
+// ---- camera_utilities.glsl:9-13 (row_major block: GLSL M * v is the plain
+// row-major product) ----
+PT_FN v3 pt_camera_ray_origin(v2 tc, const float* m) {
+	float px = 2.0f * tc.x - 1.0f, py = 2.0f * tc.y - 1.0f;
+	float r[4];
+	for (int i = 0; i != 4; ++i)
+		r[i] = ((m[4 * i + 0] * px + m[4 * i + 1] * py) + m[4 * i + 2] * 0.0f) + m[4 * i + 3] * 1.0f;
+	return mk3(r[0] / r[3], r[1] / r[3], r[2] / r[3]);
+}
+
+// ---- camera_utilities.glsl:24-44 (GLSL m[c][r] is element 4 * r + c) ----
+PT_FN v3 pt_camera_ray_direction(v2 tc, const float* m) {
+	float dx = 2.0f * tc.x - 1.0f, dy = 2.0f * tc.y - 1.0f;
+	v3 d;
+	d.x = (m[4 * 1 + 1] * m[4 * 3 + 2] - m[4 * 3 + 1] * m[4 * 1 + 2]) * dx;
+	d.x += (m[4 * 3 + 1] * m[4 * 0 + 2] - m[4 * 0 + 1] * m[4 * 3 + 2]) * dy;
+	d.x += m[4 * 0 + 1] * m[4 * 1 + 2] - m[4 * 1 + 1] * m[4 * 0 + 2];
+	d.y = (m[4 * 3 + 0] * m[4 * 1 + 2] - m[4 * 1 + 0] * m[4 * 3 + 2]) * dx;
+	d.y += (m[4 * 0 + 0] * m[4 * 3 + 2] - m[4 * 3 + 0] * m[4 * 0 + 2]) * dy;
+	d.y += m[4 * 1 + 0] * m[4 * 0 + 2] - m[4 * 0 + 0] * m[4 * 1 + 2];
+	d.z = (m[4 * 1 + 0] * m[4 * 3 + 1] - m[4 * 3 + 0] * m[4 * 1 + 1]) * dx;
+	d.z += (m[4 * 3 + 0] * m[4 * 0 + 1] - m[4 * 0 + 0] * m[4 * 3 + 1]) * dy;
+	d.z += m[4 * 0 + 0] * m[4 * 1 + 1] - m[4 * 1 + 0] * m[4 * 0 + 1];
+	return normalize(d);
+}
+
+// ---- pathtrace.frag.glsl:365-386: seed, Gaussian pixel jitter, camera ray ----
+PT_FN void pt_primary_ray(const PtConstants& c, uint32_t x, uint32_t y, uint32_t frame_index, uint32_t& sx, uint32_t& sy, v3* origin, v3* dir) {
+	sx = x ^ (frame_index << 16);
+	sy = y ^ ((frame_index + 237u) << 16);
+	v2 randoms = pt_random(sx, sy);
+	randoms.x = 2.0f * randoms.x - 1.0f;
+	randoms.y = 2.0f * randoms.y - 1.0f;
+	float scale = 0.9f * sqrtf(2.0f);
+	float jx = ((float) x + 0.5f) + scale * pt_erfinv(randoms.x);
+	float jy = ((float) y + 0.5f) + scale * pt_erfinv(randoms.y);
+	if (c.camera_type <= 1) {
+		v2 tc = mk2(jx * c.inv_viewport_size[0], jy * c.inv_viewport_size[1]);
+		*origin = pt_camera_ray_origin(tc, c.projection_to_world_space);
+		*dir = pt_camera_ray_direction(tc, c.world_to_projection_space);
+	}
+	else {
+		PtFrame f = pt_shading_space(mk3(c.hemispherical_camera_normal[0], c.hemispherical_camera_normal[1], c.hemispherical_camera_normal[2]));
+		*origin = mk3(c.camera_pos[0], c.camera_pos[1], c.camera_pos[2]);
+		float factor_y = (c.camera_type == 3) ? 2.0f : 1.0f;
+		*dir = pt_to_world(f, pt_sample_hemisphere_spherical(mk2(jx * 1.0f * c.inv_viewport_size[0], jy * factor_y * c.inv_viewport_size[1])));
+	}
+}
+
+
+// ---- mesh_quantization.glsl:4-11 ----
+PT_FN v3 pt_dequantize_position(u32x2 q, const float* factor, const float* summand) {
+	float px = (float) (q.x & 0x1fffffu);
+	float py = (float) (((q.x >> 21) & 0x7ffu) | ((q.y & 0x3ffu) << 11));
+	float pz = (float) ((q.y >> 10) & 0x1fffffu);
+	return mk3(fmaf(px, factor[0], summand[0]), fmaf(py, factor[1], summand[1]), fmaf(pz, factor[2], summand[2]));
+}
+
+// ---- mesh_quantization.glsl:16-31 ----
+PT_FN v3 pt_dequantize_normal(float ox, float oy) {
+	const float factor = 2.0f * (65534.0f / 65535.0f);
+	const float summand = -(32768.0f / 65535.0f) * factor;
+	ox = fmaf(ox, factor, summand);
+	oy = fmaf(oy, factor, summand);
+	v3 n = mk3(ox, oy, (1.0f - fabsf(ox)) - fabsf(oy));
+	float sign_x = (ox >= 0.0f) ? 1.0f : -1.0f, sign_y = (oy >= 0.0f) ? 1.0f : -1.0f;
+	if (n.z < 0.0f) {
+		float nx = (1.0f - fabsf(n.y)) * sign_x, ny = (1.0f - fabsf(n.x)) * sign_y;
+		n.x = nx;
+		n.y = ny;
+	}
+	return normalize(n);
+}
+
+
+// ---- texture(): shading_data.glsl:74-76 with the sampler of
+// src/main.c:864-873 (linear filtering, REPEAT addressing). Blocks are decoded
+// by hand with 8-bit integer palettes; filtering is bilinear on mip 0 with
+// float weights. ----
+
+// BC1 block (two RGB565 endpoints + 16 2-bit codes) -> 8-bit RGB of one texel
+PT_FN void pt_decode_bc1(uint32_t w0, uint32_t w1, uint32_t px, uint32_t py, uint32_t* r, uint32_t* g, uint32_t* b) {
+	uint32_t c0 = w0 & 0xffffu, c1 = w0 >> 16;
+	uint32_t code = (w1 >> (2 * (4 * py + px))) & 3u;
+	uint32_t r0 = ((c0 >> 8) & 0xf8u) | (c0 >> 13), g0 = ((c0 >> 3) & 0xfcu) | ((c0 >> 9) & 3u), b0 = ((c0 << 3) & 0xf8u) | ((c0 >> 2) & 7u);
+	uint32_t r1 = ((c1 >> 8) & 0xf8u) | (c1 >> 13), g1 = ((c1 >> 3) & 0xfcu) | ((c1 >> 9) & 3u), b1 = ((c1 << 3) & 0xf8u) | ((c1 >> 2) & 7u);
+	bool four = c0 > c1;
+	if (code == 0) { *r = r0; *g = g0; *b = b0; }
+	else if (code == 1) { *r = r1; *g = g1; *b = b1; }
+	else if (code == 2) {
+		if (four) { *r = (2 * r0 + r1) / 3; *g = (2 * g0 + g1) / 3; *b = (2 * b0 + b1) / 3; }
+		else { *r = (r0 + r1) / 2; *g = (g0 + g1) / 2; *b = (b0 + b1) / 2; }
+	}
+	else {
+		if (four) { *r = (r0 + 2 * r1) / 3; *g = (g0 + 2 * g1) / 3; *b = (b0 + 2 * b1) / 3; }
+		else { *r = *g = *b = 0; }
+	}
+}
+
+// BC4 block (two 8-bit endpoints + 16 3-bit codes) -> 8-bit value of one texel
+PT_FN uint32_t pt_decode_bc4(uint32_t w0, uint32_t w1, uint32_t px, uint32_t py) {
+	uint32_t a0 = w0 & 0xffu, a1 = (w0 >> 8) & 0xffu;
+	uint64_t bits = ((uint64_t) w1 << 16) | (w0 >> 16);
+	uint32_t code = (uint32_t) (bits >> (3 * (4 * py + px))) & 7u;
+	if (code == 0) return a0;
+	if (code == 1) return a1;
+	if (a0 > a1) return ((8 - code) * a0 + (code - 1) * a1) / 7;
+	if (code == 6) return 0;
+	if (code == 7) return 255;
+	return ((6 - code) * a0 + (code - 1) * a1) / 5;
+}
+
+// Mip payloads start on 16-byte boundaries of the blob, so blocks can be
+// read with aligned 8- and 16-byte loads
+PT_FN v3 pt_fetch_texel(const PtSceneView& s, const PtTexture& t, int32_t x, int32_t y) {
+	uint32_t ux = (uint32_t) x & (t.width - 1), uy = (uint32_t) y & (t.height - 1);
+	uint32_t blocks_x = (t.width + 3) / 4;
+	uint64_t block = (uint64_t) (uy / 4) * blocks_x + ux / 4;
+	if (t.format == 141) {
+		u32x4 w = *(const u32x4*) (s.texture_blob + t.mip_offsets[0] + block * 16);
+		uint32_t r = pt_decode_bc4(w.x, w.y, ux & 3, uy & 3);
+		uint32_t g = pt_decode_bc4(w.z, w.w, ux & 3, uy & 3);
+		return mk3((float) r / 255.0f, (float) g / 255.0f, 0.0f);
+	}
+	u32x2 w = *(const u32x2*) (s.texture_blob + t.mip_offsets[0] + block * 8);
+	uint32_t r, g, b;
+	pt_decode_bc1(w.x, w.y, ux & 3, uy & 3, &r, &g, &b);
+	if (t.format == 132)
+		return mk3(s.srgb_to_linear[r], s.srgb_to_linear[g], s.srgb_to_linear[b]);
+	return mk3((float) r / 255.0f, (float) g / 255.0f, (float) b / 255.0f);
+}
+
+PT_FN v3 pt_sample_texture(const PtSceneView& s, uint32_t texture_index, v2 uv) {
+	const PtTexture& t = s.textures[texture_index];
+	float x = uv.x * (float) t.width - 0.5f, y = uv.y * (float) t.height - 0.5f;
+	float fx0 = floorf(x), fy0 = floorf(y);
+	float wx = x - fx0, wy = y - fy0;
+	int32_t x0 = (int32_t) fx0, y0 = (int32_t) fy0;
+	v3 t00 = pt_fetch_texel(s, t, x0, y0), t10 = pt_fetch_texel(s, t, x0 + 1, y0);
+	v3 t01 = pt_fetch_texel(s, t, x0, y0 + 1), t11 = pt_fetch_texel(s, t, x0 + 1, y0 + 1);
+	v3 top = t00 * (1.0f - wx) + t10 * wx;
+	v3 bottom = t01 * (1.0f - wx) + t11 * wx;
+	return top * (1.0f - wy) + bottom * wy;
+}
+
+
+// ---- shading_data.glsl:19-39 ----
+struct PtShadingData {
+	v3 pos, normal, out_dir;
+	float lambert_out;
+	v3 emission, diffuse_albedo, fresnel_0;
+	float roughness;
+};
+
+// ---- shading_data.glsl:51-103 ----
+PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants& c, uint32_t triangle_index, float bary_u, float bary_v, bool front, v3 out_dir) {
+	PtShadingData s;
+	float barys[3] = { (1.0f - bary_u) - bary_v, bary_u, bary_v };
+	v3 poss[3];
+	v2 tcs[3];
+	s.pos = mk3(0.0f, 0.0f, 0.0f);
+	v3 normal_geo = mk3(0.0f, 0.0f, 0.0f);
+	v2 tc = mk2(0.0f, 0.0f);
+	for (int i = 0; i != 3; ++i) {
+		uint64_t vert = (uint64_t) triangle_index * 3 + i;
+		u32x2 qp = scene.positions[vert];
+		u32x2 qn = scene.normals_uvs[vert];
+		float n0 = (float) (qn.x & 0xffffu) / 65535.0f, n1 = (float) (qn.x >> 16) / 65535.0f;
+		float t0 = (float) (qn.y & 0xffffu) / 65535.0f, t1 = (float) (qn.y >> 16) / 65535.0f;
+		poss[i] = pt_dequantize_position(qp, c.dequantization_factor, c.dequantization_summand);
+		s.pos = s.pos + poss[i] * barys[i];
+		normal_geo = normal_geo + pt_dequantize_normal(n0, n1) * barys[i];
+		tcs[i] = mk2(t0 * 8.0f + 0.0f, t1 * -8.0f + 1.0f);
+		tc.x += barys[i] * tcs[i].x;
+		tc.y += barys[i] * tcs[i].y;
+	}
+	normal_geo = normalize(normal_geo);
+	uint32_t material = scene.materials[triangle_index];
+	v3 base_color = pt_sample_texture(scene, 3 * material + 0, tc);
+	v3 specular = pt_sample_texture(scene, 3 * material + 1, tc);
+	v3 normal_tex = pt_sample_texture(scene, 3 * material + 2, tc);
+	v3 normal_local;
+	normal_local.x = normal_tex.x * 2.0f - 1.0f;
+	normal_local.y = normal_tex.y * 2.0f - 1.0f;
+	normal_local.z = sqrtf(fmaxf(0.0f, (1.0f - normal_local.x * normal_local.x) - normal_local.y * normal_local.y));
+	// mat2(e1, e2) holds e1 and e2 as columns: [0][0] = e1.x, [1][0] = e2.x
+	v2 e1 = mk2(tcs[1].x - tcs[0].x, tcs[1].y - tcs[0].y), e2 = mk2(tcs[2].x - tcs[0].x, tcs[2].y - tcs[0].y);
+	v3 pre_tangent_0 = cross(normal_geo, poss[1] - poss[0]);
+	v3 pre_tangent_1 = cross(normal_geo, poss[0] - poss[2]);
+	v3 tangent_0 = pre_tangent_1 * e1.x + pre_tangent_0 * e2.x;
+	v3 tangent_1 = pre_tangent_1 * e1.y + pre_tangent_0 * e2.y;
+	float mean_length = sqrtf(0.5f * (dot(tangent_0, tangent_0) + dot(tangent_1, tangent_1)));
+	normal_local.z *= fmaxf(1.0e-8f, mean_length);
+	s.normal = normalize((tangent_0 * normal_local.x + tangent_1 * normal_local.y) + normal_geo * normal_local.z);
+	s.normal = front ? s.normal : -s.normal;
+	s.out_dir = out_dir;
+	float normal_offset = fmaxf(0.0f, 1.0e-3f - dot(s.normal, s.out_dir));
+	s.normal = normalize(mk3(fmaf(normal_offset, s.out_dir.x, s.normal.x), fmaf(normal_offset, s.out_dir.y, s.normal.y), fmaf(normal_offset, s.out_dir.z, s.normal.z)));
+	s.lambert_out = dot(s.normal, s.out_dir);
+	float metalicity = specular.z;
+	s.diffuse_albedo = base_color - base_color * metalicity;
+	s.fresnel_0 = mk3(0.02f, 0.02f, 0.02f) * (1.0f - metalicity) + base_color * metalicity;
+	s.roughness = fmaxf(0.006f, specular.y * specular.y);
+	s.emission = (material == scene.emission_material_index)
+		? mk3(c.emission_material_radiance[0], c.emission_material_radiance[1], c.emission_material_radiance[2])
+		: mk3(0.0f, 0.0f, 0.0f);
+	return s;
+}
+
+
+// ---- brdfs.glsl:7-12, per channel ----
+PT_FN float pt_fresnel_schlick(float f_0, float f_90, float lambert) {
+	float flip_1 = 1.0f - lambert;
+	float flip_2 = flip_1 * flip_1;
+	float flip_5 = flip_2 * flip_1 * flip_2;
+	return flip_5 * (f_90 - f_0) + f_0;
+}
+
+// ---- brdfs.glsl:19-46 ----
+PT_FN v3 pt_frostbite_brdf(const PtShadingData& s, v3 in_dir) {
+	float lambert_in = dot(s.normal, in_dir);
+	if (fminf(lambert_in, s.lambert_out) < 0.0f)
+		return mk3(0.0f, 0.0f, 0.0f);
+	v3 half_dir = normalize(in_dir + s.out_dir);
+	float half_dot_out = dot(half_dir, s.out_dir);
+	float f_90 = (half_dot_out * half_dot_out) * (2.0f * s.roughness) + 0.5f;
+	float fresnel_diffuse = pt_fresnel_schlick(1.0f, f_90, s.lambert_out) * pt_fresnel_schlick(1.0f, f_90, lambert_in);
+	v3 brdf = s.diffuse_albedo * fresnel_diffuse;
+	float half_dot_normal = dot(half_dir, s.normal);
+	float roughness_2 = s.roughness * s.roughness;
+	float ggx = (roughness_2 * half_dot_normal - half_dot_normal) * half_dot_normal + 1.0f;
+	ggx = roughness_2 / (ggx * ggx);
+	float masking = lambert_in * sqrtf((s.lambert_out - roughness_2 * s.lambert_out) * s.lambert_out + roughness_2);
+	float shadowing = s.lambert_out * sqrtf((lambert_in - roughness_2 * lambert_in) * lambert_in + roughness_2);
+	float smith = 0.5f / (masking + shadowing);
+	float l = fmaxf(0.0f, half_dot_out);
+	v3 fresnel = mk3(pt_fresnel_schlick(s.fresnel_0.x, 1.0f, l), pt_fresnel_schlick(s.fresnel_0.y, 1.0f, l), pt_fresnel_schlick(s.fresnel_0.z, 1.0f, l));
+	brdf = brdf + fresnel * (ggx * smith);
+	return brdf * (1.0f / PT_PI);
+}
+
+// ---- brdfs.glsl:58-75 with roughness equal on both axes ----
+PT_FN v3 pt_sample_ggx_vndf(v3 out_dir, float roughness, v2 randoms) {
+	v3 out_dir_std = normalize(mk3(out_dir.x * roughness, out_dir.y * roughness, out_dir.z));
+	float azimuth = (2.0f * PT_PI) * randoms.x - PT_PI;
+	float z = 1.0f - randoms.y * (1.0f + out_dir_std.z);
+	float sine = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+	float sa, ca;
+	pt_sincos(azimuth, &sa, &ca);
+	v3 half_dir_std = mk3(sine * ca, sine * sa, z) + out_dir_std;
+	return normalize(mk3(half_dir_std.x * roughness, half_dir_std.y * roughness, half_dir_std.z));
+}
+
+// ---- brdfs.glsl:88-99 ----
+PT_FN float pt_ggx_vndf_density(float lambert_out, float half_dot_normal, float half_dot_out, float roughness) {
+	if (half_dot_normal < 0.0f)
+		return 0.0f;
+	float roughness_2 = roughness * roughness;
+	float flip_roughness_2 = 1.0f - roughness * roughness;
+	float length_M_inv_out_2 = roughness_2 + flip_roughness_2 * lambert_out * lambert_out;
+	float D_vis_std = fmaxf(0.0f, half_dot_out) * (2.0f / PT_PI) / (lambert_out + sqrtf(length_M_inv_out_2));
+	float length_M_half_2 = 1.0f - flip_roughness_2 * half_dot_normal * half_dot_normal;
+	return D_vis_std * roughness_2 / (length_M_half_2 * length_M_half_2);
+}
+
+// ---- brdfs.glsl:104-107: -reflect(o, h) with reflect(I, N) = I - 2 dot(N, I) N ----
+PT_FN v3 pt_sample_ggx_in_dir(v3 out_dir, float roughness, v2 randoms) {
+	v3 half_dir = pt_sample_ggx_vndf(out_dir, roughness, randoms);
+	return -(out_dir - half_dir * (2.0f * dot(half_dir, out_dir)));
+}
+
+// ---- brdfs.glsl:112-121 ----
+PT_FN float pt_ggx_in_dir_density(float lambert_out, v3 out_dir, v3 in_dir, v3 normal, float roughness) {
+	v3 half_dir = normalize(in_dir + out_dir);
+	float half_dot_out = dot(half_dir, out_dir);
+	float half_dot_normal = dot(half_dir, normal);
+	float density = pt_ggx_vndf_density(lambert_out, half_dot_normal, half_dot_out, roughness);
+	return density / (4.0f * half_dot_out);
+}
+
+// ---- brdfs.glsl:139-146 ----
+PT_FN v3 pt_sample_hemisphere_psa(v2 randoms) {
+	float azimuth = (2.0f * PT_PI) * randoms.x - PT_PI;
+	float radius = sqrtf(randoms.y);
+	float z = sqrtf(1.0f - radius * radius);
+	float sa, ca;
+	pt_sincos(azimuth, &sa, &ca);
+	return mk3(radius * ca, radius * sa, z);
+}
+
+// ---- brdfs.glsl:151-153 ----
+PT_FN float pt_hemisphere_psa_density(float z) { return (1.0f / PT_PI) * fmaxf(0.0f, z); }
+
+// ---- brdfs.glsl:158-164 ----
+PT_FN float pt_diffuse_sampling_probability(const PtShadingData& s) {
+	return fminf(0.5f, dot(s.diffuse_albedo, mk3(0.2126f, 0.7152f, 0.0722f)));
+}
+
+// ---- brdfs.glsl:174-199 ----
+PT_FN v3 pt_sample_frostbite_brdf(const PtShadingData& s, v2 randoms) {
+	PtFrame frame = pt_shading_space(s.normal);
+	float diffuse_prob = pt_diffuse_sampling_probability(s);
+	if (randoms.x < diffuse_prob) {
+		randoms.x /= diffuse_prob;
+		return pt_to_world(frame, pt_sample_hemisphere_psa(randoms));
+	}
+	randoms.x = (randoms.x - diffuse_prob) / (1.0f - diffuse_prob);
+	v3 local_out_dir = pt_to_local(frame, s.out_dir);
+	return pt_to_world(frame, pt_sample_ggx_in_dir(local_out_dir, s.roughness, randoms));
+}
+
+// ---- brdfs.glsl:203-208; mix(a, b, t) = a * (1 - t) + b * t ----
+PT_FN float pt_frostbite_brdf_density(const PtShadingData& s, v3 sampled_dir) {
+	float diffuse_prob = pt_diffuse_sampling_probability(s);
+	float specular_density = pt_ggx_in_dir_density(s.lambert_out, s.out_dir, sampled_dir, s.normal, s.roughness);
+	float diffuse_density = pt_hemisphere_psa_density(dot(s.normal, sampled_dir));
+	return specular_density * (1.0f - diffuse_prob) + diffuse_density * diffuse_prob;
+}
+
+
+// ---- pathtrace.frag.glsl:69-83 ----
+PT_FN float pt_spherical_light_importance(f32x4 light, v3 shading_pos, v3 normal) {
+	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
+	if (dot(normal, center_dir) < -light.w)
+		return 0.0f;
+	float center_dist_2 = dot(center_dir, center_dir);
+	float sin_2 = light.w * light.w / center_dist_2;
+	return sin_2 / (1.0f + sqrtf(fmaxf(0.0f, 1.0f - sin_2)));
+}
+
+// ---- pathtrace.frag.glsl:95-106 ----
+PT_FN v3 pt_sample_spherical_light(f32x4 light, float importance, v3 shading_pos, v2 randoms) {
+	float azimuth = (2.0f * PT_PI) * randoms.x - PT_PI;
+	float z = 1.0f - importance * randoms.y;
+	float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+	float sa, ca;
+	pt_sincos(azimuth, &sa, &ca);
+	PtFrame frame = pt_shading_space(normalize(mk3(light.x, light.y, light.z) - shading_pos));
+	return pt_to_world(frame, mk3(r * ca, r * sa, z));
+}
+
+// ---- pathtrace.frag.glsl:120-143 ----
+PT_FN v3 pt_sample_lights(const PtSceneView& scene, float* out_total_importance, v3 shading_pos, v3 normal, v2 randoms) {
+	float total = 0.0f;
+	for (uint32_t i = 0; i != scene.light_count; ++i)
+		total += pt_spherical_light_importance(scene.lights[i], shading_pos, normal);
+	*out_total_importance = total;
+	float target_importance = randoms.x * total;
+	float prefix_importance = 0.0f;
+	for (uint32_t i = 0; i != scene.light_count; ++i) {
+		f32x4 light = scene.lights[i];
+		float importance = pt_spherical_light_importance(light, shading_pos, normal);
+		prefix_importance += importance;
+		if (prefix_importance > target_importance) {
+			randoms.x = ((target_importance + importance) - prefix_importance) / importance;
+			return pt_sample_spherical_light(light, importance, shading_pos, randoms);
+		}
+	}
+	return mk3(0.0f, 0.0f, 0.0f);
+}
+
+// ---- pathtrace.frag.glsl:150-175 ----
+PT_FN float pt_lights_density(const PtSceneView& scene, float total_importance, v3 shading_pos, v3 sampled_dir, bool is_light_dir) {
+	if (total_importance <= 0.0f)
+		return 0.0f;
+	float light_count = 0.0f;
+	for (uint32_t i = 0; i != scene.light_count; ++i) {
+		f32x4 light = scene.lights[i];
+		v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
+		float center_dist_2 = dot(center_dir, center_dir);
+		float center_dot_dir = dot(center_dir, sampled_dir);
+		float radius_2 = light.w * light.w;
+		float in_sphere = center_dist_2 - radius_2;
+		float discriminant = center_dot_dir * center_dot_dir - in_sphere;
+		light_count += (discriminant >= 0.0f && in_sphere >= 0.0f && center_dot_dir >= 0.0f) ? 1.0f : 0.0f;
+	}
+	if (is_light_dir)
+		light_count = fmaxf(1.0f, light_count);
+	return light_count / (2.0f * PT_PI * total_importance);
+}
+
+
+// What shading one path vertex produces (the body of one iteration of the
+// loops at pathtrace.frag.glsl:224-362 after the extension ray has returned)
+struct PtVertexResult {
+	bool continues;   // an extension ray leaves this vertex
+	v3 next_origin, next_dir;
+	bool shadow;      // a shadow ray leaves this vertex (NEE only)
+	v3 shadow_dir;
+	v3 shadow_weight; // throughput * brdf
+	float shadow_factor; // lambert / (light density + brdf density)
+};
+
+// Shades vertex k (1-based) of a path. radiance, throughput, nee_throughput
+// and the seed are the path state and are updated in place. hit_prim ==
+// 0xffffffff means the extension ray left the scene.
+PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants& c, int strategy, uint32_t path_length, uint32_t k,
+	uint32_t hit_prim, float hit_u, float hit_v, bool hit_front, v3 ray_dir,
+	v3& radiance, v3& throughput, v3& nee_throughput, uint32_t& sx, uint32_t& sy)
+{
+	PtVertexResult r;
+	r.continues = false;
+	r.shadow = false;
+	r.next_origin = r.next_dir = r.shadow_dir = r.shadow_weight = mk3(0.0f, 0.0f, 0.0f);
+	r.shadow_factor = 0.0f;
+	// In the NEE estimator emission is weighted by nee_throughput, in the
+	// others by throughput (pathtrace.frag.glsl:231,265,293,323)
+	v3 emission_weight = (strategy == PT_STRATEGY_NEE) ? nee_throughput : throughput;
+	if (hit_prim == 0xffffffffu) {
+		radiance = radiance + emission_weight * mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
+		return r;
+	}
+	PtShadingData s = pt_shading_data(scene, c, hit_prim, hit_u, hit_v, hit_front, -ray_dir);
+	radiance = radiance + emission_weight * s.emission;
+	if (k >= path_length)
+		return r;
+	r.next_origin = s.pos;
+	if (strategy == PT_STRATEGY_SPHERICAL || strategy == PT_STRATEGY_PSA) {
+		// pathtrace.frag.glsl:234-240 and :268-274
+		PtFrame frame = pt_shading_space(s.normal);
+		v2 randoms = pt_random(sx, sy);
+		v3 sampled_dir = (strategy == PT_STRATEGY_SPHERICAL) ? pt_sample_hemisphere_spherical(randoms) : pt_sample_hemisphere_psa(randoms);
+		r.next_dir = pt_to_world(frame, sampled_dir);
+		float lambert_in = sampled_dir.z;
+		float density = (strategy == PT_STRATEGY_SPHERICAL) ? pt_hemisphere_spherical_density(sampled_dir.z) : pt_hemisphere_psa_density(sampled_dir.z);
+		throughput = throughput * ((pt_frostbite_brdf(s, r.next_dir) * lambert_in) / density);
+		r.continues = true;
+	}
+	else if (strategy == PT_STRATEGY_BRDF) {
+		// pathtrace.frag.glsl:296-304
+		r.next_dir = pt_sample_frostbite_brdf(s, pt_random(sx, sy));
+		float density = pt_frostbite_brdf_density(s, r.next_dir);
+		float lambert_in = dot(s.normal, r.next_dir);
+		if (lambert_in <= 0.0f)
+			return r;
+		throughput = throughput * ((pt_frostbite_brdf(s, r.next_dir) * lambert_in) / density);
+		r.continues = true;
+	}
+	else {
+		// pathtrace.frag.glsl:326-355
+		float total_light_importance;
+		v3 light_dir = pt_sample_lights(scene, &total_light_importance, s.pos, s.normal, pt_random(sx, sy));
+		float lambert_in_0 = dot(s.normal, light_dir);
+		if (lambert_in_0 > 0.0f) {
+			float light_density_0 = pt_lights_density(scene, total_light_importance, s.pos, light_dir, true);
+			float brdf_density_0 = pt_frostbite_brdf_density(s, light_dir);
+			r.shadow = true;
+			r.shadow_dir = light_dir;
+			r.shadow_weight = throughput * pt_frostbite_brdf(s, light_dir);
+			r.shadow_factor = lambert_in_0 / (light_density_0 + brdf_density_0);
+		}
+		r.next_dir = pt_sample_frostbite_brdf(s, pt_random(sx, sy));
+		float lambert_in_1 = dot(s.normal, r.next_dir);
+		if (lambert_in_1 <= 0.0f)
+			return r;
+		float light_density_1 = pt_lights_density(scene, total_light_importance, s.pos, r.next_dir, false);
+		float brdf_density_1 = pt_frostbite_brdf_density(s, r.next_dir);
+		v3 brdf_lambert_1 = pt_frostbite_brdf(s, r.next_dir) * lambert_in_1;
+		nee_throughput = throughput * (brdf_lambert_1 / (light_density_1 + brdf_density_1));
+		throughput = throughput * (brdf_lambert_1 * (1.0f / brdf_density_1));
+		r.continues = true;
+	}
+	return r;
+}

@@ -1,0 +1,166 @@
+// Closest-hit ray traversal of the 8-wide compressed BVH. Replaces the ray
+// queries of the reference (rayQueryInitializeEXT(..., gl_RayFlagsOpaqueEXT,
+// 0xff, origin, 1e-3, dir, 1e38) + rayQueryProceedEXT at
+// src/shaders/pathtrace.frag.glsl:183-185 and :205-207).
+//
+// Intersection semantics (the reference leaves them to the Vulkan driver):
+// watertight ray/triangle test of Woop, Benthin and Wald (JCGT 2013) in single
+// precision, t strictly inside (tmin, tmax), the closest t wins and equal t is
+// broken by the lower triangle index, so the result does not depend on the
+// shape of the BVH or the traversal order.
+#pragma once
+#include "pt_common.h"
+
+struct PtHit {
+	uint32_t prim; // index of the triangle in the scene file, 0xffffffff: miss
+	float t;
+	float u, v;    // barycentric weights of vertex 1 and vertex 2
+	bool front;
+};
+
+struct PtRayShear {
+	int kx, ky, kz;
+	float sx, sy, sz;
+};
+
+PT_FN PtRayShear pt_ray_shear(v3 dir) {
+	PtRayShear r;
+	float ax = fabsf(dir.x), ay = fabsf(dir.y), az = fabsf(dir.z);
+	r.kz = (ax > ay) ? ((ax > az) ? 0 : 2) : ((ay > az) ? 1 : 2);
+	r.kx = (r.kz == 2) ? 0 : r.kz + 1;
+	r.ky = (r.kx == 2) ? 0 : r.kx + 1;
+	if (comp(dir, r.kz) < 0.0f) {
+		int swap = r.kx;
+		r.kx = r.ky;
+		r.ky = swap;
+	}
+	float dz = comp(dir, r.kz);
+	r.sx = comp(dir, r.kx) / dz;
+	r.sy = comp(dir, r.ky) / dz;
+	r.sz = 1.0f / dz;
+	return r;
+}
+
+PT_FN void pt_intersect_triangle(PtHit& hit, const PtRayShear& r, v3 origin, v3 p0, v3 p1, v3 p2, uint32_t prim, float tmin) {
+	v3 a = p0 - origin, b = p1 - origin, c = p2 - origin;
+	float az = comp(a, r.kz), bz = comp(b, r.kz), cz = comp(c, r.kz);
+	float ax = comp(a, r.kx) - r.sx * az, ay = comp(a, r.ky) - r.sy * az;
+	float bx = comp(b, r.kx) - r.sx * bz, by = comp(b, r.ky) - r.sy * bz;
+	float cx = comp(c, r.kx) - r.sx * cz, cy = comp(c, r.ky) - r.sy * cz;
+	float u = cx * by - cy * bx;
+	float v = ax * cy - ay * cx;
+	float w = bx * ay - by * ax;
+	if ((u < 0.0f || v < 0.0f || w < 0.0f) && (u > 0.0f || v > 0.0f || w > 0.0f))
+		return;
+	float det = (u + v) + w;
+	if (det == 0.0f)
+		return;
+	float tz = (u * (r.sz * az) + v * (r.sz * bz)) + w * (r.sz * cz);
+	float rcp_det = 1.0f / det;
+	float t = tz * rcp_det;
+	if (!(t > tmin))
+		return;
+	if (t < hit.t || (t == hit.t && prim < hit.prim)) {
+		hit.t = t;
+		hit.prim = prim;
+		hit.u = v * rcp_det;
+		hit.v = w * rcp_det;
+		// det is minus the signed area of the triangle seen along the ray;
+		// front faces have dot(cross(p1 - p0, p2 - p0), dir) < 0
+		hit.front = det > 0.0f;
+	}
+}
+
+PT_FN float pt_byte_to_float(uint32_t word, int byte) { return (float) ((word >> (8 * byte)) & 0xffu); }
+
+// Stack must provide push(u32x2), pop() and empty(). An entry is a group of
+// sibling nodes still to visit: x = index of the first inner child of their
+// parent, y = pending children (bits 24-31, most urgent highest) | imask.
+// With COUNT_VISITS, visits[0] and visits[1] receive the numbers of nodes
+// fetched and triangles tested.
+template <bool COUNT_VISITS, typename Stack>
+PT_FN PtHit pt_trace_closest(const PtNode* nodes, const PtTri* tris, uint32_t triangle_count, v3 origin, v3 dir, float tmin, float tmax, Stack& stack, uint32_t* visits) {
+	PtHit hit;
+	hit.prim = 0xffffffffu;
+	hit.t = tmax;
+	hit.u = hit.v = 0.0f;
+	hit.front = false;
+	if (triangle_count == 0)
+		return hit;
+	PtRayShear shear = pt_ray_shear(dir);
+	// The box test may be conservative, so tiny direction components are
+	// clamped to keep reciprocals finite
+	float cdx = (fabsf(dir.x) > 1.0e-30f) ? dir.x : copysignf(1.0e-30f, dir.x);
+	float cdy = (fabsf(dir.y) > 1.0e-30f) ? dir.y : copysignf(1.0e-30f, dir.y);
+	float cdz = (fabsf(dir.z) > 1.0e-30f) ? dir.z : copysignf(1.0e-30f, dir.z);
+	float idx = 1.0f / cdx, idy = 1.0f / cdy, idz = 1.0f / cdz;
+	bool neg_x = cdx < 0.0f, neg_y = cdy < 0.0f, neg_z = cdz < 0.0f;
+	uint32_t octinv = 7u - ((neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u));
+	u32x2 ngroup;
+	ngroup.x = 0;
+	ngroup.y = 0x80000000u;
+	while (true) {
+		u32x2 tgroup;
+		tgroup.x = tgroup.y = 0;
+		if (ngroup.y & 0xff000000u) {
+			uint32_t bit = 31u - (uint32_t) __builtin_clz(ngroup.y);
+			ngroup.y &= ~(1u << bit);
+			if (ngroup.y & 0xff000000u)
+				stack.push(ngroup);
+			uint32_t slot = (bit - 24u) ^ octinv;
+			uint32_t rel = (uint32_t) __builtin_popcount(ngroup.y & 0xffu & ((1u << slot) - 1u));
+			const u32x4* words = (const u32x4*) &nodes[ngroup.x + rel];
+			if (COUNT_VISITS)
+				++visits[0];
+			u32x4 w0 = words[0], w1 = words[1], w2 = words[2], w3 = words[3], w4 = words[4];
+			float sx = pt_as_float((w0.w & 0xffu) << 23), sy = pt_as_float(((w0.w >> 8) & 0xffu) << 23), sz = pt_as_float(((w0.w >> 16) & 0xffu) << 23);
+			uint32_t imask = w0.w >> 24;
+			float ax = idx * sx, ay = idy * sy, az = idz * sz;
+			float bx = (pt_as_float(w0.x) - origin.x) * idx, by = (pt_as_float(w0.y) - origin.y) * idy, bz = (pt_as_float(w0.z) - origin.z) * idz;
+			uint32_t qlox[2] = { w2.x, w2.y }, qloy[2] = { w2.z, w2.w }, qloz[2] = { w3.x, w3.y };
+			uint32_t qhix[2] = { w3.z, w3.w }, qhiy[2] = { w4.x, w4.y }, qhiz[2] = { w4.z, w4.w };
+			uint32_t meta[2] = { w1.z, w1.w };
+			uint32_t hitmask = 0;
+#pragma unroll
+			for (int i = 0; i != 8; ++i) {
+				uint32_t m = (meta[i >> 2] >> (8 * (i & 3))) & 0xffu;
+				float lx = pt_byte_to_float(qlox[i >> 2], i & 3), hx = pt_byte_to_float(qhix[i >> 2], i & 3);
+				float ly = pt_byte_to_float(qloy[i >> 2], i & 3), hy = pt_byte_to_float(qhiy[i >> 2], i & 3);
+				float lz = pt_byte_to_float(qloz[i >> 2], i & 3), hz = pt_byte_to_float(qhiz[i >> 2], i & 3);
+				float nx = fmaf(neg_x ? hx : lx, ax, bx), fx = fmaf(neg_x ? lx : hx, ax, bx);
+				float ny = fmaf(neg_y ? hy : ly, ay, by), fy = fmaf(neg_y ? ly : hy, ay, by);
+				float nz = fmaf(neg_z ? hz : lz, az, bz), fz = fmaf(neg_z ? lz : hz, az, bz);
+				float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+				float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
+				if (m != 0 && tn <= tf) {
+					if (imask & (1u << i))
+						hitmask |= 1u << (24u + ((uint32_t) i ^ octinv));
+					else
+						hitmask |= (m >> 5) << (m & 31u);
+				}
+			}
+			ngroup.x = w1.x;
+			ngroup.y = (hitmask & 0xff000000u) | imask;
+			tgroup.x = w1.y;
+			tgroup.y = hitmask & 0x00ffffffu;
+		}
+		while (tgroup.y) {
+			uint32_t bit = (uint32_t) __builtin_ctz(tgroup.y);
+			tgroup.y &= tgroup.y - 1u;
+			const u32x4* words = (const u32x4*) &tris[tgroup.x + bit];
+			if (COUNT_VISITS)
+				++visits[1];
+			u32x4 t0 = words[0], t1 = words[1], t2 = words[2];
+			v3 p0 = mk3(pt_as_float(t0.x), pt_as_float(t0.y), pt_as_float(t0.z));
+			v3 p1 = mk3(pt_as_float(t0.w), pt_as_float(t1.x), pt_as_float(t1.y));
+			v3 p2 = mk3(pt_as_float(t1.z), pt_as_float(t1.w), pt_as_float(t2.x));
+			pt_intersect_triangle(hit, shear, origin, p0, p1, p2, t2.y, tmin);
+		}
+		if (!(ngroup.y & 0xff000000u)) {
+			if (stack.empty())
+				break;
+			ngroup = stack.pop();
+		}
+	}
+	return hit;
+}

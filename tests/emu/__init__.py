@@ -1,0 +1,130 @@
+"""ctypes binding of tests/emu/libpt_emu.so: the per-thread kernel bodies of the HIP library run on the host.
+
+TEST INFRASTRUCTURE ONLY. It lets the CPU test suite check BVH construction, traversal and shading logic of the
+gfx950 kernels against the oracle without a GPU. The product library never loads it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libpt_emu.so")
+_CSRC = os.path.join(_HERE, "..", "..", "path_tracer_amd", "csrc")
+
+
+def build(force=False):
+    sources = [os.path.join(_HERE, "pt_emu.cpp")] + [os.path.join(_CSRC, n) for n in ("pt_common.h", "pt_bvh_build.h", "pt_trace.h", "pt_shade.h")]
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in sources):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                               "-o", _LIB, os.path.join(_HERE, "pt_emu.cpp")])
+
+
+class _Texture(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("format", C.c_uint32), ("mip_count", C.c_uint32),
+                ("payload", C.c_void_p), ("mip_offsets", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.emu_create_scene.restype = C.c_void_p
+        _lib.emu_create_scene.argtypes = [C.c_uint64, C.c_uint64] + [C.c_void_p] * 6 + [C.c_uint32]
+        _lib.emu_destroy_scene.argtypes = [C.c_void_p]
+        _lib.emu_set_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        _lib.emu_bvh_info.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.emu_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.emu_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.emu_render.restype = C.c_uint64
+        _lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+        _lib.emu_shading_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.emu_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
+        _lib.emu_log.restype = C.c_float
+        _lib.emu_log.argtypes = [C.c_float]
+        _lib.emu_erfinv.restype = C.c_float
+        _lib.emu_erfinv.argtypes = [C.c_float]
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class EmuScene:
+    def __init__(self, scene):
+        self.scene = scene
+        self._keep = []
+        textures = (_Texture * max(1, len(scene.textures)))()
+        for i, t in enumerate(scene.textures):
+            payload = np.ascontiguousarray(t.payload)
+            offsets = np.ascontiguousarray(t.mip_offsets, dtype=np.uint64)
+            self._keep += [payload, offsets]
+            textures[i] = _Texture(t.width, t.height, t.format, t.mip_count, payload.ctypes.data, offsets.ctypes.data)
+        f = np.ascontiguousarray(scene.dequantization_factor, np.float32)
+        s = np.ascontiguousarray(scene.dequantization_summand, np.float32)
+        p = np.ascontiguousarray(scene.positions, np.uint32)
+        n = np.ascontiguousarray(scene.normals_uvs, np.uint16)
+        m = np.ascontiguousarray(scene.materials, np.uint8)
+        self.handle = lib().emu_create_scene(len(scene.material_names), scene.triangle_count, _ptr(f), _ptr(s), _ptr(p), _ptr(n), _ptr(m), C.byref(textures), len(scene.textures))
+
+    def close(self):
+        if self.handle:
+            lib().emu_destroy_scene(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    def set_lights(self, lights):
+        lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 4)
+        lib().emu_set_lights(self.handle, _ptr(lights), len(lights))
+
+    def bvh_info(self):
+        out = np.zeros(3, np.uint32)
+        lib().emu_bvh_info(self.handle, _ptr(out))
+        return {"node_count": int(out[0]), "depth": int(out[1]), "max_stack": int(out[2])}
+
+    def trace_rays(self, origins, directions):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        tri = np.zeros(len(o), np.int32)
+        tuv = np.zeros((len(o), 3), np.float32)
+        front = np.zeros(len(o), np.uint8)
+        visits = np.zeros(2, np.uint64)
+        lib().emu_trace_rays(self.handle, _ptr(o), _ptr(d), len(o), _ptr(tri), _ptr(tuv), _ptr(front), _ptr(visits))
+        return tri, tuv, front, visits
+
+    def primary_hits(self, constants, frame_index):
+        w, h = int(constants.viewport_size[0]), int(constants.viewport_size[1])
+        tri = np.zeros((h, w), np.int32)
+        barys = np.zeros((h, w, 2), np.float32)
+        front = np.zeros((h, w), np.uint8)
+        lib().emu_primary_hits(self.handle, C.byref(constants), frame_index, _ptr(tri), _ptr(barys), _ptr(front))
+        return tri, barys, front
+
+    def render(self, constants, strategy=3, path_length=4, emission_material_index=None, first_frame_index=0, frame_count=1, frame_stride=1, accum=None):
+        w, h = int(constants.viewport_size[0]), int(constants.viewport_size[1])
+        accumulate = accum is not None
+        if accum is None:
+            accum = np.zeros((h, w, 4), np.float32)
+        if emission_material_index is None:
+            emission_material_index = self.scene.emission_material_index
+        rays = lib().emu_render(self.handle, C.byref(constants), strategy, path_length, emission_material_index, first_frame_index, frame_count, frame_stride, int(accumulate), _ptr(accum))
+        return accum, rays
+
+    def shading_data(self, constants, triangles, barys, front, out_dirs, emission_material_index=None):
+        triangles = np.ascontiguousarray(triangles, np.int32).reshape(-1)
+        barys = np.ascontiguousarray(barys, np.float32).reshape(-1, 2)
+        front = np.ascontiguousarray(front, np.uint8).reshape(-1)
+        out_dirs = np.ascontiguousarray(out_dirs, np.float32).reshape(-1, 3)
+        if emission_material_index is None:
+            emission_material_index = self.scene.emission_material_index
+        out = np.zeros((len(triangles), 20), np.float32)
+        lib().emu_shading_data(self.handle, C.byref(constants), emission_material_index, _ptr(triangles), _ptr(barys), _ptr(front), _ptr(out_dirs), len(triangles), _ptr(out))
+        return out

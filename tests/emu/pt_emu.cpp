@@ -1,0 +1,244 @@
+// Host-side execution of the per-thread kernel bodies of path_tracer_amd/csrc
+// for unit tests on machines without a GPU. TEST INFRASTRUCTURE: this file is
+// never part of libpt_hip.so and nothing in the product calls it. It runs the
+// same BVH build steps, traversal and shading functions that the gfx950
+// kernels run, one "thread" after the other, so that their logic can be
+// checked against the CPU oracle before any GPU time is spent.
+#include "../../path_tracer_amd/csrc/pt_common.h"
+#include "../../path_tracer_amd/csrc/pt_bvh_build.h"
+#include "../../path_tracer_amd/csrc/pt_trace.h"
+#include "../../path_tracer_amd/csrc/pt_shade.h"
+#include <algorithm>
+#include <vector>
+#include <cstdio>
+
+struct EmuStack {
+	u32x2 data[256];
+	uint32_t sp = 0, max_sp = 0;
+	void push(u32x2 e) { data[sp++] = e; if (sp > max_sp) max_sp = sp; }
+	u32x2 pop() { return data[--sp]; }
+	bool empty() const { return sp == 0; }
+};
+
+struct EmuTexture { uint32_t width, height, format, mip_count; const uint8_t* payload; const uint64_t* mip_offsets; };
+
+struct EmuScene {
+	uint32_t n;
+	std::vector<u32x2> positions, normals_uvs;
+	std::vector<uint8_t> materials;
+	std::vector<PtTexture> textures;
+	std::vector<uint8_t> blob;
+	std::vector<float> srgb;
+	std::vector<f32x4> lights;
+	std::vector<PtNode> nodes;
+	std::vector<PtTri> tris;
+	uint32_t node_count, depth, max_stack;
+	uint32_t emission_material_index;
+	PtSceneView view() const {
+		PtSceneView v;
+		v.nodes = nodes.data(); v.tris = tris.data(); v.triangle_count = n;
+		v.positions = positions.data(); v.normals_uvs = normals_uvs.data(); v.materials = materials.data();
+		v.textures = textures.data(); v.texture_blob = blob.data(); v.srgb_to_linear = srgb.data();
+		v.lights = lights.data(); v.light_count = (uint32_t) lights.size(); v.emission_material_index = emission_material_index;
+		return v;
+	}
+};
+
+extern "C" {
+
+EmuScene* emu_create_scene(uint64_t material_count, uint64_t triangle_count, const float* factor, const float* summand,
+	const uint32_t* positions, const uint16_t* normals_uvs, const uint8_t* materials, const EmuTexture* textures, uint32_t texture_count)
+{
+	EmuScene* s = new EmuScene();
+	uint32_t n = s->n = (uint32_t) triangle_count;
+	s->positions.resize(3 * (size_t) n + 1);
+	s->normals_uvs.resize(3 * (size_t) n + 1);
+	memcpy(s->positions.data(), positions, 24 * (size_t) n);
+	memcpy(s->normals_uvs.data(), normals_uvs, 24 * (size_t) n);
+	s->materials.assign(materials, materials + n);
+	s->materials.push_back(0);
+	s->srgb.resize(256);
+	for (int i = 0; i != 256; ++i) {
+		double c = i / 255.0;
+		s->srgb[i] = (float) ((c <= 0.04045) ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+	}
+	s->textures.resize(texture_count ? texture_count : 1);
+	for (uint32_t i = 0; i != texture_count; ++i) {
+		const EmuTexture& t = textures[i];
+		PtTexture& d = s->textures[i];
+		d.width = t.width; d.height = t.height; d.format = t.format; d.mip_count = t.mip_count;
+		uint32_t block = (t.format == 141) ? 16 : 8;
+		for (uint32_t m = 0; m != t.mip_count; ++m) {
+			uint32_t w = std::max(t.width >> m, 4u), h = std::max(t.height >> m, 4u);
+			uint64_t size = (uint64_t) ((w + 3) / 4) * ((h + 3) / 4) * block;
+			size_t offset = (s->blob.size() + 15) & ~(size_t) 15;
+			s->blob.resize(offset + size);
+			memcpy(&s->blob[offset], t.payload + t.mip_offsets[m], size);
+			d.mip_offsets[m] = offset;
+		}
+	}
+	s->blob.resize(s->blob.size() + 16);
+	s->emission_material_index = 0;
+	s->nodes.resize(n ? n : 1);
+	s->tris.resize(n ? n : 1);
+	s->node_count = 1; s->depth = 1; s->max_stack = 0;
+	if (n == 0) {
+		memset(&s->nodes[0], 0, sizeof(PtNode));
+		return s;
+	}
+	// The build, step by step as in pt_build_bvh() of pt_hip.hip
+	PtBuild b;
+	memset(&b, 0, sizeof(b));
+	b.n = n;
+	b.positions = s->positions.data();
+	memcpy(b.factor, factor, 12); memcpy(b.summand, summand, 12);
+	std::vector<float> verts(9 * (size_t) n), box(12 * (size_t) n);
+	std::vector<uint32_t> bounds(6), order(n), left(n), right(n), parent(2 * (size_t) n), range_first(n), range_last(n), flags(n, 0), task_binary(n), counters(2);
+	std::vector<uint64_t> keys(n);
+	b.verts = verts.data(); b.bounds = bounds.data(); b.keys = keys.data(); b.order = order.data();
+	b.left = left.data(); b.right = right.data(); b.parent = parent.data(); b.range_first = range_first.data(); b.range_last = range_last.data();
+	b.box = box.data(); b.flags = flags.data(); b.nodes = s->nodes.data(); b.tris = s->tris.data(); b.task_binary = task_binary.data(); b.counters = counters.data();
+	for (int j = 0; j != 3; ++j) { bounds[j] = 0xffffffffu; bounds[3 + j] = 0; }
+	for (uint32_t i = 0; i != n; ++i) {
+		float lo[3], hi[3];
+		pt_build_dequantize(b, i, lo, hi);
+		for (int j = 0; j != 3; ++j) {
+			bounds[j] = std::min(bounds[j], pt_float_to_key(lo[j]));
+			bounds[3 + j] = std::max(bounds[3 + j], pt_float_to_key(hi[j]));
+		}
+	}
+	PtSceneBounds sb = pt_build_get_bounds(b.bounds);
+	for (uint32_t i = 0; i != n; ++i) { keys[i] = pt_build_morton(b, sb, i); order[i] = i; }
+	std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return keys[x] < keys[y]; });
+	{
+		std::vector<uint64_t> sorted(n);
+		for (uint32_t i = 0; i != n; ++i) sorted[i] = keys[order[i]];
+		keys.swap(sorted);
+		b.keys = keys.data();
+	}
+	for (uint32_t i = 0; i + 1 < n; ++i) pt_build_radix_tree(b, i);
+	// Visit leaves in a scrambled order to exercise the arrival counters
+	for (uint32_t i = 0; i != n; ++i) {
+		uint32_t k = (uint32_t) (((uint64_t) i * 2654435761u) % n);
+		(void) k;
+	}
+	for (uint32_t i = 0; i != n; ++i)
+		pt_build_refit(b, sb.pad, i, [](uint32_t* flag) { return (*flag)++; });
+	counters[0] = 1; counters[1] = 0; task_binary[0] = 0;
+	uint32_t level_begin = 0, level_end = 1, depth = 0;
+	while (level_begin < level_end) {
+		for (uint32_t i = level_begin; i != level_end; ++i)
+			pt_build_collapse(b, sb.pad, i,
+				[&](uint32_t c) { uint32_t r = counters[0]; counters[0] += c; return r; },
+				[&](uint32_t c) { uint32_t r = counters[1]; counters[1] += c; return r; });
+		level_begin = level_end;
+		level_end = counters[0];
+		++depth;
+	}
+	s->node_count = level_end;
+	s->depth = depth;
+	if (counters[1] != n)
+		printf("emu: collapse wrote %u of %u triangles\n", counters[1], n);
+	return s;
+}
+
+void emu_destroy_scene(EmuScene* s) { delete s; }
+
+void emu_set_lights(EmuScene* s, const float* lights, uint32_t count) {
+	s->lights.resize(count);
+	if (count) memcpy(s->lights.data(), lights, 16 * (size_t) count);
+}
+
+void emu_bvh_info(EmuScene* s, uint32_t* out) { out[0] = s->node_count; out[1] = s->depth; out[2] = s->max_stack; }
+
+void emu_trace_rays(EmuScene* s, const float* origins, const float* directions, uint32_t count, int32_t* triangles, float* tuv, uint8_t* front, uint64_t* visits_out) {
+	uint64_t total[2] = { 0, 0 };
+	for (uint32_t i = 0; i != count; ++i) {
+		EmuStack stack;
+		uint32_t visits[2] = { 0, 0 };
+		PtHit hit = pt_trace_closest<true>(s->nodes.data(), s->tris.data(), s->n, mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]),
+			mk3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]), 1.0e-3f, 1e38f, stack, visits);
+		s->max_stack = std::max(s->max_stack, stack.max_sp);
+		total[0] += visits[0]; total[1] += visits[1];
+		triangles[i] = (int32_t) hit.prim;
+		tuv[3 * i] = hit.t; tuv[3 * i + 1] = hit.u; tuv[3 * i + 2] = hit.v;
+		front[i] = hit.front;
+	}
+	if (visits_out) { visits_out[0] = total[0]; visits_out[1] = total[1]; }
+}
+
+void emu_primary_hits(EmuScene* s, const PtConstants* c, uint32_t frame_index, int32_t* triangles, float* barys, uint8_t* front) {
+	uint32_t w = (uint32_t) c->viewport_size[0], h = (uint32_t) c->viewport_size[1];
+	for (uint32_t y = 0; y != h; ++y) for (uint32_t x = 0; x != w; ++x) {
+		uint32_t sx, sy;
+		v3 o, d;
+		pt_primary_ray(*c, x, y, frame_index, sx, sy, &o, &d);
+		EmuStack stack;
+		PtHit hit = pt_trace_closest<false>(s->nodes.data(), s->tris.data(), s->n, o, d, 1.0e-3f, 1e38f, stack, NULL);
+		size_t i = (size_t) y * w + x;
+		triangles[i] = (int32_t) hit.prim;
+		barys[2 * i] = hit.u; barys[2 * i + 1] = hit.v;
+		front[i] = hit.front;
+	}
+}
+
+// One path per pixel and frame, vertex by vertex, with the radiance updates
+// in the order in which the wavefront kernels apply them
+uint64_t emu_render(EmuScene* s, const PtConstants* c, int strategy, uint32_t path_length, uint32_t emission_material_index,
+	uint32_t first_frame, uint32_t frame_count, uint32_t frame_stride, int accumulate, float* accum)
+{
+	s->emission_material_index = emission_material_index;
+	PtSceneView scene = s->view();
+	uint32_t w = (uint32_t) c->viewport_size[0], h = (uint32_t) c->viewport_size[1];
+	uint64_t rays = 0;
+	for (uint32_t y = 0; y != h; ++y) for (uint32_t x = 0; x != w; ++x) {
+		float* pixel = &accum[4 * ((size_t) y * w + x)];
+		for (uint32_t f = 0; f != frame_count; ++f) {
+			uint32_t sx, sy;
+			v3 o, d;
+			pt_primary_ray(*c, x, y, first_frame + f * frame_stride, sx, sy, &o, &d);
+			v3 throughput = mk3(1, 1, 1), nee = mk3(1, 1, 1), radiance = mk3(0, 0, 0);
+			for (uint32_t k = 1; k <= path_length; ++k) {
+				EmuStack stack;
+				PtHit hit = pt_trace_closest<false>(scene.nodes, scene.tris, s->n, o, d, 1.0e-3f, 1e38f, stack, NULL);
+				++rays;
+				PtVertexResult r = pt_shade_vertex(scene, *c, strategy, path_length, k, hit.prim, hit.u, hit.v, hit.front, d, radiance, throughput, nee, sx, sy);
+				if (r.shadow) {
+					EmuStack sstack;
+					PtHit sh = pt_trace_closest<false>(scene.nodes, scene.tris, s->n, r.next_origin, r.shadow_dir, 1.0e-3f, 1e38f, sstack, NULL);
+					++rays;
+					v3 emission;
+					if (sh.prim == 0xffffffffu) emission = mk3(c->sky_radiance[0], c->sky_radiance[1], c->sky_radiance[2]);
+					else if (scene.materials[sh.prim] == emission_material_index) emission = mk3(c->emission_material_radiance[0], c->emission_material_radiance[1], c->emission_material_radiance[2]);
+					else emission = mk3(0, 0, 0);
+					radiance = radiance + (r.shadow_weight * emission) * r.shadow_factor;
+				}
+				if (!r.continues) break;
+				o = r.next_origin; d = r.next_dir;
+			}
+			if (f == 0 && !accumulate) { pixel[0] = radiance.x; pixel[1] = radiance.y; pixel[2] = radiance.z; pixel[3] = 1.0f; }
+			else { pixel[0] += radiance.x; pixel[1] += radiance.y; pixel[2] += radiance.z; }
+		}
+	}
+	return rays;
+}
+
+void emu_shading_data(EmuScene* s, const PtConstants* c, uint32_t emission_material_index, const int32_t* triangles, const float* barys, const uint8_t* front, const float* out_dirs, uint32_t count, float* out) {
+	s->emission_material_index = emission_material_index;
+	PtSceneView scene = s->view();
+	for (uint32_t i = 0; i != count; ++i) {
+		PtShadingData d = pt_shading_data(scene, *c, (uint32_t) triangles[i], barys[2 * i], barys[2 * i + 1], front[i] != 0, mk3(out_dirs[3 * i], out_dirs[3 * i + 1], out_dirs[3 * i + 2]));
+		float* o = &out[20 * (size_t) i];
+		o[0] = d.pos.x; o[1] = d.pos.y; o[2] = d.pos.z; o[3] = d.normal.x; o[4] = d.normal.y; o[5] = d.normal.z;
+		o[6] = d.out_dir.x; o[7] = d.out_dir.y; o[8] = d.out_dir.z; o[9] = d.lambert_out;
+		o[10] = d.emission.x; o[11] = d.emission.y; o[12] = d.emission.z;
+		o[13] = d.diffuse_albedo.x; o[14] = d.diffuse_albedo.y; o[15] = d.diffuse_albedo.z;
+		o[16] = d.fresnel_0.x; o[17] = d.fresnel_0.y; o[18] = d.fresnel_0.z; o[19] = d.roughness;
+	}
+}
+
+void emu_sincos(float x, float* s, float* c) { pt_sincos(x, s, c); }
+float emu_log(float x) { return pt_log(x); }
+float emu_erfinv(float x) { return pt_erfinv(x); }
+
+}

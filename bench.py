@@ -1,0 +1,178 @@
+"""Headline benchmark: Mrays/s and samples/s of the wavefront path tracer on MI355X.
+
+python bench.py --gpus N --steps K --warmup W
+One step = one pass of the hot path over one batch: --spp-per-step frames of the workload at full resolution.
+For N > 1 the driver launches one process per GPU (torch.distributed, backend "nccl" = RCCL); every rank renders
+its own interleaved slice of frame indices (weak scaling: per-GPU work is fixed) and the accumulation targets are
+summed with one all-reduce inside the timed region. Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DATA_ROOT = os.path.join(ROOT, "tests", "golden")
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=32)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--spp-per-step", type=int, default=32)
+    p.add_argument("--path-length", type=int, default=4)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def trace_bytes_per_ray(kind, nodes_per_ray, tris_per_ray, node_bytes, tri_bytes):
+    """Algorithmic bytes one traversal kernel moves per ray (DESIGN.md, section 'Kernels')."""
+    if kind == "extension":
+        stream = 32 + 16  # ray record read, hit record written
+    else:
+        stream = 48 + 32 + 1  # shadow record read, radiance read-modify-write, material byte
+    return stream + nodes_per_ray * node_bytes + tris_per_ray * tri_bytes
+
+
+def cpu_baseline(args, threads):
+    """The CPU oracle on a bounded sample of the same workload (reported baseline, not the target)."""
+    import oracle
+    from oracle import formats
+    data = os.path.join(DATA_ROOT, "data")
+    scene = formats.load_scene(os.path.join(data, "cornell_box.vks"), os.path.join(data, "cornell_box_textures"))
+    lights = formats.load_lights(os.path.join(data, "cornell_box.lights"))
+    spec = formats.load_rt_save(os.path.join(data, "saves", "cornell_box", "default.rt_save"))
+    width, height, spp = args.width // 4, args.height // 4, 8
+    constants = oracle.write_constants(spec, width, height, scene, lights)
+    cpu_scene = oracle.OracleScene(scene)
+    begin = time.perf_counter()
+    _, rays = cpu_scene.render(constants, lights, strategy=3, path_length=args.path_length, first_frame_index=2696, frame_count=spp, threads=threads)
+    seconds = time.perf_counter() - begin
+    return {"value": rays / seconds * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "CPU oracle, Cornell box %dx%d, %d spp, NEE, path length %d, %d rays in %.2f s" % (width, height, spp, args.path_length, rays, seconds)}
+
+
+def main():
+    args = parse_args()
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    from path_tracer_amd import hip_api, host_api, multi_gpu
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+
+    spec = host_api.quickload(os.path.join(DATA_ROOT, "data", "saves", "cornell_box", "default.rt_save"))
+    renderer = host_api.Renderer(spec, DATA_ROOT, device=local_rank, width=args.width, height=args.height,
+                                 sampling_strategy=hip_api.SAMPLING_STRATEGY_NEE, path_length=args.path_length)
+    constants = renderer.constants()
+    lib = hip_api.lib()
+    import ctypes as C
+
+    spp = args.spp_per_step
+    next_frame = [spec.frame_index + 1]
+
+    def render_step(accumulate):
+        # Sample slices: rank r renders frames base + r, base + r + G, ...
+        first, count, stride = multi_gpu.frame_slice(rank, world_size, next_frame[0], spp * world_size)
+        code = lib.pt_render_samples(renderer.device_scene, C.byref(constants), first, count, stride, int(accumulate))
+        if code:
+            raise RuntimeError("pt_render_samples failed")
+        next_frame[0] += spp * world_size
+
+    def barrier():
+        renderer.synchronize()
+        torch.cuda.synchronize()
+        if world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # One instrumented step for the per-ray node and triangle counts (deterministic given the frame indices)
+    renderer.set_instrumentation(kernel_timing=False, visit_counters=True)
+    renderer.reset_statistics()
+    render_step(False)
+    renderer.synchronize()
+    profile = renderer.statistics()
+    renderer.set_instrumentation(kernel_timing=False, visit_counters=False)
+    for _ in range(args.warmup):
+        render_step(True)
+    tensor = multi_gpu.accumulation_tensor(renderer)
+    if world_size > 1:
+        dist.all_reduce(tensor)  # warm up the communicator
+    renderer.set_instrumentation(kernel_timing=True, visit_counters=False)
+    renderer.reset_statistics()
+    barrier()
+    begin = time.perf_counter()
+    for step in range(args.steps):
+        render_step(step != 0)
+    multi_gpu.all_reduce_accumulation(renderer, total_sample_count=args.steps * spp * world_size)
+    barrier()
+    seconds = time.perf_counter() - begin
+    stats = renderer.statistics()
+    rays = stats.extension_rays + stats.shadow_rays
+    totals = torch.tensor([float(rays), float(stats.paths), seconds], dtype=torch.float64, device="cuda")
+    if world_size > 1:
+        maximum = totals.clone()
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+        dist.all_reduce(maximum, op=dist.ReduceOp.MAX)
+        seconds = float(maximum[2])
+    total_rays, total_paths = float(totals[0]), float(totals[1])
+
+    if rank == 0:
+        info = renderer.bvh_info()
+        kinds = (("extension", 1, profile.extension_rays, 0), ("shadow", 2, profile.shadow_rays, 1))
+        kernels = {}
+        for name, index, profile_rays, slot in kinds:
+            launches = stats.kernel_launches[index]
+            timed_rays = stats.extension_rays if name == "extension" else stats.shadow_rays
+            if not launches or not profile_rays:
+                continue
+            nodes = profile.nodes_visited[slot] / profile_rays
+            tris = profile.triangles_tested[slot] / profile_rays
+            bytes_per_ray = trace_bytes_per_ray(name, nodes, tris, info.node_bytes, info.triangle_bytes)
+            avg_ms = stats.kernel_ms[index] / launches
+            kernels[name] = {"total_ms": stats.kernel_ms[index], "launches": int(launches), "avg_ms": avg_ms, "rays_per_launch": timed_rays / launches,
+                             "nodes_per_ray": nodes, "tris_per_ray": tris, "bytes_per_ray": bytes_per_ray,
+                             "achieved_gbs": bytes_per_ray * timed_rays / launches / (avg_ms * 1e-3) * 1e-9}
+        dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
+        d = kernels[dominant]
+        result = {
+            "metric": "Mrays/s", "value": total_rays / seconds * 1e-6, "unit": "Mrays/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": seconds / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "Cornell box scene file of the reference (fixture copy of data/cornell_box.vks, its textures, lights and quicksave)",
+            "config": {"workload": "Cornell box %dx%d, NEE + MIS, path length %d, %d spp per step per GPU, frames %d.." % (args.width, args.height, args.path_length, spp, spec.frame_index + 1),
+                       "spp_total": args.steps * spp * world_size, "parallelism": "sample slices x%d + all-reduce" % world_size},
+            "samples_per_s": total_paths / seconds,
+            "rays_per_path": total_rays / total_paths,
+            "roofline": {"bound": "hbm", "kernel": "k_trace_%s" % dominant, "achieved": d["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": d["achieved_gbs"] / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": d["avg_ms"], "rays_per_launch": d["rays_per_launch"], "bytes_per_ray": d["bytes_per_ray"],
+                         "nodes_per_ray": d["nodes_per_ray"], "triangles_per_ray": d["tris_per_ray"]},
+            "kernel_ms": {name: stats.kernel_ms[i] for i, name in enumerate(hip_api.KERNEL_NAMES)},
+            "bvh": {"nodes": info.node_count, "triangles": info.triangle_count, "depth": info.depth, "build_ms": info.build_ms},
+        }
+        if not args.no_cpu_baseline and world_size == 1:
+            result["cpu_baseline"] = cpu_baseline(args, min(16, os.cpu_count() or 1))
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    renderer.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,8 +144,9 @@ typedef struct {
 	uint64_t extension_rays;
 	uint64_t shadow_rays;
 	uint64_t paths;
-	uint64_t nodes_visited;
-	uint64_t triangles_tested;
+	/* index 0: extension rays, 1: shadow rays */
+	uint64_t nodes_visited[2];
+	uint64_t triangles_tested[2];
 	uint64_t shaded_hits;
 	/* index: 0 raygen, 1 extension trace, 2 shadow trace, 3 shade, 4 resolve */
 	double kernel_ms[5];

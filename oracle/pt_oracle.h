@@ -107,7 +107,7 @@ float oracle_log(float x);
 float oracle_erfinv(float x);
 
 /* Host-side restatements (src/camera.c:102-167, src/math_utilities.c:16-64,
- * 197-203, src/main.c:629-676). camera is the 60-byte camera_t of
+ * 197-203, src/main.c:629-676). camera is the 64-byte camera_t of
  * src/camera.h:42-63 inside scene_spec_t. */
 typedef struct {
 	float angles[3];

@@ -161,7 +161,7 @@ struct PtTraceArgs {
 	uint32_t stack_overflow_stride, stack_capacity;
 	uint32_t bounce;  // index into ext_count / shadow_count
 	uint32_t parity;  // which ray queue holds this bounce
-	unsigned long long* visit_counters; // [0] nodes, [1] triangles, or NULL
+	unsigned long long* visit_counters; // nodes, triangles of extension rays [0], [1] and of shadow rays [2], [3], or NULL
 };
 
 // pathtrace.frag.glsl:365-386 for every path of the batch
@@ -244,8 +244,8 @@ __global__ void __launch_bounds__(PT_BLOCK) k_trace_shadow(PtTraceArgs a) {
 	uint32_t visits[2] = { 0, 0 };
 	PtHit hit = pt_trace_closest<COUNT_VISITS>(a.scene.nodes, a.scene.tris, a.scene.triangle_count, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 1.0e-3f, 1e38f, stack, visits);
 	if (COUNT_VISITS) {
-		atomicAdd(&a.visit_counters[0], (unsigned long long) visits[0]);
-		atomicAdd(&a.visit_counters[1], (unsigned long long) visits[1]);
+		atomicAdd(&a.visit_counters[2], (unsigned long long) visits[0]);
+		atomicAdd(&a.visit_counters[3], (unsigned long long) visits[1]);
 	}
 	const PtConstants& c = *a.constants;
 	v3 emission;
@@ -269,7 +269,7 @@ struct PtShadeArgs {
 	uint32_t path_length;
 	uint32_t k;       // 1-based path vertex; reads ext queue k - 1
 	uint32_t parity;  // ray queue of this bounce; the next one is parity ^ 1
-	unsigned long long* visit_counters; // [2] counts shaded hits, or NULL
+	unsigned long long* visit_counters; // [4] counts shaded hits, or NULL
 };
 
 __global__ void __launch_bounds__(PT_BLOCK) k_shade(PtShadeArgs a) {
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(PtShadeArgs a) {
 		v3 throughput = mk3(s0.x, s0.y, s0.z), nee_throughput = mk3(s1.x, s1.y, s1.z), radiance = mk3(rad.x, rad.y, rad.z);
 		uint32_t sx = pt_as_uint(s0.w), sy = pt_as_uint(s1.w);
 		if (a.visit_counters && hit.x != PT_INVALID)
-			atomicAdd(&a.visit_counters[2], 1ull);
+			atomicAdd(&a.visit_counters[4], 1ull);
 		r = pt_shade_vertex(a.scene, *a.constants, a.strategy, a.path_length, a.k,
 			hit.x, pt_as_float(hit.y), pt_as_float(hit.z), hit.w != 0, mk3(d.x, d.y, d.z),
 			radiance, throughput, nee_throughput, sx, sy);
@@ -758,7 +758,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 			break;
 		uint64_t n = s->triangle_count;
 		if (pt_alloc(&s->positions, 3 * n) || pt_alloc(&s->normals_uvs, 3 * n) || pt_alloc(&s->materials, n)
-			|| pt_alloc(&s->counters, PT_COUNTER_WORDS) || pt_alloc(&s->constants, 1) || pt_alloc(&s->visit_counters, 4)
+			|| pt_alloc(&s->counters, PT_COUNTER_WORDS) || pt_alloc(&s->constants, 1) || pt_alloc(&s->visit_counters, 8)
 			|| pt_alloc(&s->srgb_to_linear, 256) || pt_alloc(&s->lights, 1))
 			break;
 		if (n) {
@@ -767,7 +767,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 				|| hipMemcpyAsync(s->materials, material_indices, n, hipMemcpyHostToDevice, s->stream) != hipSuccess)
 				break;
 		}
-		if (hipMemsetAsync(s->visit_counters, 0, 4 * sizeof(unsigned long long), s->stream) != hipSuccess)
+		if (hipMemsetAsync(s->visit_counters, 0, 8 * sizeof(unsigned long long), s->stream) != hipSuccess)
 			break;
 		// sRGB decoding table for VK_FORMAT_BC1_RGB_SRGB_BLOCK textures
 		float table[256];
@@ -1062,11 +1062,13 @@ extern "C" int pt_get_statistics(pt_scene_t* s, pt_statistics_t* out) {
 		return 1;
 	if (pt_synchronize(s))
 		return 1;
-	unsigned long long visits[4] = { 0, 0, 0, 0 };
+	unsigned long long visits[8];
 	PT_CHECK(hipMemcpy(visits, s->visit_counters, sizeof(visits), hipMemcpyDeviceToHost));
-	s->stats.nodes_visited = visits[0];
-	s->stats.triangles_tested = visits[1];
-	s->stats.shaded_hits = visits[2];
+	s->stats.nodes_visited[0] = visits[0];
+	s->stats.triangles_tested[0] = visits[1];
+	s->stats.nodes_visited[1] = visits[2];
+	s->stats.triangles_tested[1] = visits[3];
+	s->stats.shaded_hits = visits[4];
 	*out = s->stats;
 	return 0;
 }
@@ -1077,7 +1079,7 @@ extern "C" int pt_reset_statistics(pt_scene_t* s) {
 	if (pt_synchronize(s))
 		return 1;
 	memset(&s->stats, 0, sizeof(s->stats));
-	PT_CHECK(hipMemset(s->visit_counters, 0, 4 * sizeof(unsigned long long)));
+	PT_CHECK(hipMemset(s->visit_counters, 0, 8 * sizeof(unsigned long long)));
 	return 0;
 }
 

@@ -54,7 +54,7 @@ class TextureDesc(C.Structure):
 
 class Statistics(C.Structure):
     _fields_ = [("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
-                ("nodes_visited", C.c_uint64), ("triangles_tested", C.c_uint64), ("shaded_hits", C.c_uint64),
+                ("nodes_visited", C.c_uint64 * 2), ("triangles_tested", C.c_uint64 * 2), ("shaded_hits", C.c_uint64),
                 ("kernel_ms", C.c_double * 5), ("kernel_launches", C.c_uint64 * 5)]
 
 

@@ -1,0 +1,79 @@
+"""Synthetic scenes in the .vks/.vkt data layout for tests (seeded, built in memory)."""
+import numpy as np
+
+from oracle import formats
+
+
+def encode_octahedral(normals):
+    n = normals / np.abs(normals).sum(axis=1, keepdims=True)
+    xy = n[:, :2].copy()
+    neg = n[:, 2] < 0
+    folded = (1 - np.abs(n[neg][:, 1::-1])) * np.where(n[neg][:, :2] >= 0, 1.0, -1.0)
+    xy[neg] = folded
+    # stored value 32768 <-> 0, 1 <-> -1, 65535 <-> +1 (tools/io_export_vulkan_blender28.py:36-46)
+    return np.clip(np.round(xy * 32767.0 + 32768.0), 1, 65535).astype(np.uint16)
+
+
+def quantize_positions(points):
+    lo, hi = points.min(axis=0), points.max(axis=0)
+    extent = np.maximum(hi - lo, 1e-6)
+    factor = (extent / (2 ** 21 - 1)).astype(np.float32)
+    summand = lo.astype(np.float32)
+    q = np.clip(np.round((points - lo) / factor.astype(np.float64)), 0, 2 ** 21 - 1).astype(np.uint64)
+    word0 = (q[:, 0] | ((q[:, 1] & 0x7ff) << 21)).astype(np.uint32)
+    word1 = ((q[:, 1] >> 11) | (q[:, 2] << 10)).astype(np.uint32)
+    return np.stack([word0, word1], 1), factor, summand
+
+
+def random_texture(rng, size, fmt, mips=1):
+    block = 16 if fmt == 141 else 8
+    payloads, extents, offsets, offset = [], [], [], 0
+    for m in range(mips):
+        s = max(size >> m, 4)
+        data = rng.integers(0, 256, (s // 4) * (s // 4) * block, dtype=np.uint8)
+        payloads.append(data)
+        extents.append((s, s, len(data)))
+        offsets.append(offset)
+        offset += len(data)
+    return formats.Texture(size, size, fmt, mips, extents, np.array(offsets, np.uint64), np.concatenate(payloads))
+
+
+def triangle_soup(seed=1, triangle_count=4000, material_count=3, extent=10.0, size=0.6, texture_size=32, emission_fraction=0.05):
+    """Random small triangles in a cube, random block-compressed textures, first material emits."""
+    rng = np.random.default_rng(seed)
+    centers = rng.uniform(-extent / 2, extent / 2, (triangle_count, 1, 3))
+    verts = centers + rng.normal(scale=size, size=(triangle_count, 3, 3))
+    positions, factor, summand = quantize_positions(verts.reshape(-1, 3))
+    geometric = np.cross(verts[:, 1] - verts[:, 0], verts[:, 2] - verts[:, 0])
+    geometric /= np.maximum(np.linalg.norm(geometric, axis=1, keepdims=True), 1e-12)
+    normals = np.repeat(geometric, 3, axis=0) + rng.normal(scale=0.2, size=(3 * triangle_count, 3))
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    uv = rng.integers(0, 65536, (3 * triangle_count, 2)).astype(np.uint16)
+    normals_uvs = np.concatenate([encode_octahedral(normals), uv], axis=1).astype(np.uint16)
+    materials = rng.integers(1, material_count, triangle_count).astype(np.uint8) if material_count > 1 else np.zeros(triangle_count, np.uint8)
+    materials[rng.random(triangle_count) < emission_fraction] = 0
+    names = ["_emission"] + ["material_%d" % i for i in range(1, material_count)]
+    textures = []
+    for _ in range(material_count):
+        textures += [random_texture(rng, texture_size, 132), random_texture(rng, texture_size, 131), random_texture(rng, texture_size, 141)]
+    return formats.Scene(names, triangle_count, factor, summand, positions, normals_uvs, materials, textures)
+
+
+def random_lights(seed, count, extent=10.0, radius=(0.1, 0.5)):
+    rng = np.random.default_rng(seed)
+    lights = np.zeros((count, 4), np.float32)
+    lights[:, :3] = rng.uniform(-extent / 2, extent / 2, (count, 3))
+    lights[:, 3] = rng.uniform(radius[0], radius[1], count)
+    return lights
+
+
+def look_at_spec(position, angles, frame_index=100, sky=(0.2, 0.4, 1.0), sky_strength=1.0, emission_strength=10.0, camera_type=0):
+    spec = formats.default_scene_spec()
+    spec["position"] = position
+    spec["angles"] = angles
+    spec["frame_index"] = frame_index
+    spec["sky_color"] = sky
+    spec["sky_strength"] = sky_strength
+    spec["emission_material_strength"] = emission_strength
+    spec["type"] = camera_type
+    return spec

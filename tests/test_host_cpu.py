@@ -1,0 +1,184 @@
+"""CPU-side checks of the product's host code: the C ABI library exports what its header declares, the C host
+agrees with the oracle's independent restatements (bitwise for matrices and constants) and with the numpy file
+parsers. Nothing here launches GPU work."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import formats
+from path_tracer_amd import hip_api, host_api, multi_gpu
+from tests.paths import DATA, DATA_ROOT, ROOT
+
+
+def declared_functions(header_path):
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(?:int|void\*?|void)\s+\*?\s*(pt_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    names = declared_functions(os.path.join(ROOT, "include", "pt_hip.h"))
+    assert len(names) >= 18
+    assert sorted(names) == sorted(hip_api.EXPORTED_SYMBOLS)
+    library = C.CDLL(hip_api.LIB_PATH)
+    for name in names:
+        assert hasattr(library, name), name
+
+
+def test_host_library_exports():
+    library = host_api.lib()
+    for name in host_api.EXPORTED_SYMBOLS:
+        assert hasattr(library, name), name
+
+
+def test_abi_struct_sizes():
+    assert C.sizeof(hip_api.Constants) == 784
+    assert C.sizeof(host_api.SceneSpec) == 128
+    assert C.sizeof(hip_api.Statistics) == 8 * 8 + 5 * 8 + 5 * 8
+
+
+def test_invert_mat4_bitwise_against_oracle():
+    rng = np.random.default_rng(11)
+    for _ in range(50):
+        m = rng.normal(size=16).astype(np.float32)
+        out = np.zeros(16, np.float32)
+        host_api.lib().invert_mat4(out.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p))
+        assert (out.view(np.uint32) == oracle.invert_mat4(m).reshape(16).view(np.uint32)).all()
+
+
+def all_saves():
+    saves = []
+    for root, _, files in os.walk(os.path.join(DATA, "saves")):
+        saves += [os.path.join(root, f) for f in sorted(files) if f.endswith(".rt_save")]
+    return sorted(saves)
+
+
+@pytest.mark.parametrize("save", all_saves())
+def test_quickload_and_constants_bitwise(save, cornell):
+    """Every quicksave of the reference: C host == numpy parser; constants block == oracle restatement, bit for bit."""
+    spec = host_api.quickload(save)
+    parsed = formats.load_rt_save(save)
+    assert bytes(spec) == parsed.tobytes()
+    lights = formats.load_lights(os.path.join(DATA, "Bistro_outside.lights"))
+    lit = host_api.LitScene()
+    lit.scene.header.dequantization_factor[:] = [float(v) for v in cornell.dequantization_factor]
+    lit.scene.header.dequantization_summand[:] = [float(v) for v in cornell.dequantization_summand]
+    light_array = ((C.c_float * 4) * len(lights))()
+    for i, l in enumerate(lights):
+        light_array[i][:] = [float(v) for v in l]
+    lit.spherical_lights = C.cast(light_array, C.POINTER(C.c_float * 4))
+    lit.spherical_light_count = len(lights)
+    for width, height in ((1920, 1080), (512, 512), (50, 37)):
+        targets = host_api.RenderTargets(width, height, 3)
+        constants = hip_api.Constants()
+        assert host_api.lib().write_constant_buffer(C.byref(constants), C.byref(spec), C.byref(lit), C.byref(targets)) == 0
+        expected = oracle.write_constants(parsed, width, height, cornell, lights, accum_frame_count=3)
+        assert bytes(constants) == bytes(expected)
+
+
+def test_default_scene_spec_matches_parser():
+    spec = host_api.SceneSpec()
+    host_api.lib().init_scene_spec(C.byref(spec))
+    assert bytes(spec) == formats.default_scene_spec().tobytes()
+    settings = host_api.RenderSettings()
+    host_api.lib().init_render_settings(C.byref(settings))
+    assert (settings.sampling_strategy, settings.path_length) == (3, 4)
+
+
+def test_scene_file_table():
+    paths = host_api.scene_file_paths(1)
+    assert paths == {"name": "Cornell box", "scene": "data/cornell_box.vks", "textures": "data/cornell_box_textures",
+                     "lights": "data/cornell_box.lights", "quicksave": "data/saves/cornell_box/default.rt_save"}
+    assert host_api.scene_file_paths(0)["lights"] == "data/Bistro_outside.lights"
+    outs = [C.c_char_p() for _ in range(5)]
+    assert host_api.lib().get_scene_file(99, *[C.byref(o) for o in outs]) != 0
+
+
+def test_texture_loader_against_parser():
+    directory = os.path.join(DATA, "cornell_box_textures")
+    names = sorted(os.listdir(directory))
+    paths = (C.c_char_p * len(names))(*[os.fsencode(os.path.join(directory, n)) for n in names])
+    textures = host_api.HostTextures()
+    assert host_api.lib().load_textures(C.byref(textures), paths, len(names)) == 0
+    for i, name in enumerate(names):
+        parsed = formats.load_vkt(os.path.join(directory, name))
+        t = textures.textures[i]
+        assert (t.width, t.height, t.format, t.mipmap_count) == (parsed.width, parsed.height, parsed.format, parsed.mip_count)
+        for m in range(t.mipmap_count):
+            size = t.mipmap_sizes[m]
+            assert size == parsed.mip_extents[m][2]
+            data = C.string_at(t.mipmap_data[m], size)
+            offset = int(parsed.mip_offsets[m])
+            assert data == parsed.payload[offset:offset + size].tobytes()
+    host_api.lib().free_textures(C.byref(textures))
+    assert textures.texture_count == 0
+
+
+def test_loaders_reject_bad_files(tmp_path, capfd):
+    bad = tmp_path / "bad.vkt"
+    bad.write_bytes(b"\x00" * 64)
+    paths = (C.c_char_p * 1)(os.fsencode(str(bad)))
+    textures = host_api.HostTextures()
+    assert host_api.lib().load_textures(C.byref(textures), paths, 1) != 0
+    missing = (C.c_char_p * 1)(os.fsencode(str(tmp_path / "missing.vkt")))
+    assert host_api.lib().load_textures(C.byref(textures), missing, 1) != 0
+    scene = host_api.HostScene()
+    bad_scene = tmp_path / "bad.vks"
+    bad_scene.write_bytes(b"\x01\x02\x03\x04" * 8)
+    assert host_api.lib().load_scene(C.byref(scene), 0, os.fsencode(str(bad_scene)), b".") != 0
+    assert host_api.lib().load_scene(C.byref(scene), 0, os.fsencode(str(tmp_path / "none.vks")), b".") != 0
+    assert not scene.device_scene
+    spec = host_api.SceneSpec()
+    assert host_api.lib().quickload(C.byref(spec), os.fsencode(str(tmp_path / "none.rt_save"))) != 0
+    C.CDLL(None).fflush(None)  # the C host prints through libc's buffered stdout
+    out = capfd.readouterr().out
+    assert "not a valid *.vks file" in out and "Could not open the quicksave file" in out
+
+
+def test_quicksave_round_trip(tmp_path):
+    spec = host_api.quickload(os.path.join(DATA, "saves", "bistro", "outside.rt_save"))
+    path = str(tmp_path / "copy.rt_save")
+    assert host_api.lib().quicksave(C.byref(spec), os.fsencode(path)) == 0
+    assert open(path, "rb").read() == open(os.path.join(DATA, "saves", "bistro", "outside.rt_save"), "rb").read()
+
+
+def test_image_writers(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    path = str(tmp_path / "a.png")
+    assert host_api.lib().write_png(os.fsencode(path), 53, 37, rgb.ctypes.data_as(C.c_void_p)) == 0
+    assert (np.asarray(Image.open(path)) == rgb).all()
+    big = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)  # more than one stored deflate block
+    assert host_api.lib().write_png(os.fsencode(path), 400, 300, big.ctypes.data_as(C.c_void_p)) == 0
+    assert (np.asarray(Image.open(path)) == big).all()
+    hdr = (rng.random((20, 30, 3)) * np.array([0.01, 5.0, 300.0])).astype(np.float32)
+    hdr[0, 0] = 0
+    path = str(tmp_path / "a.hdr")
+    assert host_api.lib().write_hdr(os.fsencode(path), 30, 20, hdr.ctypes.data_as(C.c_void_p)) == 0
+    raw = open(path, "rb").read()
+    header_end = raw.index(b"+X 30\n") + 6
+    assert raw.startswith(b"#?RADIANCE\n") and b"-Y 20 +X 30" in raw
+    rgbe = np.frombuffer(raw[header_end:], np.uint8).reshape(20, 30, 4).astype(np.float64)
+    decoded = rgbe[..., :3] * np.exp2(rgbe[..., 3:] - 136.0)
+    decoded[rgbe[..., 3] == 0] = 0
+    # RGBE keeps 8 bits of the largest component
+    assert np.abs(decoded - hdr).max(axis=2).max() <= np.abs(hdr).max() / 128
+    assert (np.abs(decoded - hdr).max(axis=2) <= hdr.max(axis=2) / 100 + 1e-30).all()
+
+
+def test_frame_slices_partition_the_sample_set():
+    for world in (1, 2, 3, 4, 8):
+        for total in (0, 1, 5, 8, 64, 1023):
+            covered = []
+            for rank in range(world):
+                first, count, stride = multi_gpu.frame_slice(rank, world, 2696, total)
+                assert stride == world and first == 2696 + rank
+                covered += [first + i * stride for i in range(count)]
+            assert sorted(covered) == list(range(2696, 2696 + total))
+    with pytest.raises(ValueError):
+        multi_gpu.frame_slice(4, 4, 0, 10)

@@ -1,0 +1,240 @@
+"""Pins for the CPU oracle: known answers, facts from the reference's data files, internal consistency.
+
+The reference ships no tests or golden vectors, so these are the pins that exist: the published PCG2D algorithm
+(JCGT 9(3), 2020) restated independently, values parsed from the reference's own data files, library functions
+(scipy/numpy) for the elementary functions, and agreement of the four unbiased estimators.
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.special
+
+import oracle
+from oracle import formats
+from tests.paths import DATA
+
+
+def pcg2d_python(x, y):
+    m = 0xffffffff
+    x = (1664525 * x + 1013904223) & m
+    y = (1664525 * y + 1013904223) & m
+    x = (x + 1664525 * y) & m
+    y = (y + 1664525 * x) & m
+    x ^= x >> 16
+    y ^= y >> 16
+    x = (x + 1664525 * y) & m
+    y = (y + 1664525 * x) & m
+    x ^= x >> 16
+    y ^= y >> 16
+    return x, y
+
+
+def test_pcg2d_known_answers():
+    randoms, seeds = oracle.rng_stream(0, 0, 0, 1)
+    assert (int(seeds[0, 0]), int(seeds[0, 1])) == (0x802ed074, 0xe6ee372f)
+    assert randoms[0, 0] == np.float32(0.5007143) and randoms[0, 1] == np.float32(0.90207237)
+    _, seeds = oracle.rng_stream(255, 255, 2696, 1)
+    assert (int(seeds[0, 0]), int(seeds[0, 1])) == (0x97f0d66d, 0xc37e4336)
+
+
+def test_pcg2d_against_independent_restatement():
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        x, y, f = (int(v) for v in rng.integers(0, 1 << 16, 3))
+        randoms, seeds = oracle.rng_stream(x, y, f, 5)
+        sx, sy = x ^ ((f << 16) & 0xffffffff), y ^ (((f + 237) << 16) & 0xffffffff)
+        for i in range(5):
+            sx, sy = pcg2d_python(sx, sy)
+            assert (int(seeds[i, 0]), int(seeds[i, 1])) == (sx, sy)
+            # uint -> float rounds to nearest even, then an exact scaling by 2^-32; 1.0 is reachable
+            assert randoms[i, 0] == np.float32(sx) * np.float32(2.0 ** -32)
+            assert randoms[i, 1] == np.float32(sy) * np.float32(2.0 ** -32)
+
+
+def test_frame_index_shift_drops_high_bits():
+    a, _ = oracle.rng_stream(3, 4, 5, 2)
+    b, _ = oracle.rng_stream(3, 4, 5 + (1 << 16), 2)
+    assert (a == b).all()
+
+
+def test_cornell_box_file_facts(cornell, cornell_lights, cornell_spec):
+    assert os.path.getsize(os.path.join(DATA, "cornell_box.vks")) == 64300
+    assert cornell.material_names == ["_emission", "green", "red", "white"]
+    assert cornell.triangle_count == 1310
+    assert np.bincount(cornell.materials).tolist() == [1280, 2, 2, 26]
+    assert cornell.emission_material_index == 0
+    assert len(cornell.textures) == 12
+    assert [t.format for t in cornell.textures[:3]] == [132, 131, 141]
+    assert cornell.textures[0].payload.tobytes().hex() == "7ce7bce6aaaaaaaa"
+    assert cornell_lights.shape == (1, 4)
+    np.testing.assert_allclose(cornell_lights[0], [0.278, -0.2796, 0.4788, 0.07], rtol=1e-4)
+    spec = cornell_spec[0]
+    assert spec["scene_file"] == 1 and spec["frame_index"] == 2695 and spec["type"] == 0
+    np.testing.assert_allclose(spec["position"], [0.278, 0.379, 0.2744], rtol=1e-6)
+    np.testing.assert_allclose(spec["angles"], [np.pi / 2, 0, 0], atol=1e-6)
+    assert spec["fov"] == np.float32(np.pi * float(np.float32(0.4)))
+    assert spec["emission_material_strength"] == 20.0 and spec["sky_strength"] == 0.0
+
+
+def _dequantize(scene):
+    p = scene.positions.astype(np.uint64)
+    x = (p[:, 0] & 0x1fffff).astype(np.float64)
+    y = ((p[:, 0] >> 21) | ((p[:, 1] & 0x3ff) << 11)).astype(np.float64)
+    z = ((p[:, 1] >> 10) & 0x1fffff).astype(np.float64)
+    return (np.stack([x, y, z], 1) * scene.dequantization_factor + scene.dequantization_summand).reshape(-1, 3, 3)
+
+
+def test_emission_mesh_is_the_light_sphere(cornell, cornell_lights):
+    verts = _dequantize(cornell)[cornell.materials == 0].reshape(-1, 3)
+    radius = np.linalg.norm(verts - cornell_lights[0, :3], axis=1)
+    assert np.abs(radius - cornell_lights[0, 3]).max() < 2e-4
+
+
+def test_front_face_convention_pin(cornell, cornell_lights, cornell_spec, oracle_cornell):
+    """Every stored vertex normal agrees with cross(v1 - v0, v2 - v0); a camera inside the lit room must see front faces."""
+    tris = _dequantize(cornell)
+    geometric = np.cross(tris[:, 1] - tris[:, 0], tris[:, 2] - tris[:, 0])
+    o = cornell.normals_uvs[:, :2].astype(np.float64) / 65535 * 2 * (65534 / 65535) - (32768 / 65535) * 2 * (65534 / 65535)
+    nz = 1 - np.abs(o[:, 0]) - np.abs(o[:, 1])
+    n = np.stack([o[:, 0], o[:, 1], nz], 1)
+    fold = nz < 0
+    n[fold, 0] = (1 - np.abs(o[fold, 1])) * np.where(o[fold, 0] >= 0, 1, -1)
+    n[fold, 1] = (1 - np.abs(o[fold, 0])) * np.where(o[fold, 1] >= 0, 1, -1)
+    stored = n.reshape(-1, 3, 3).mean(axis=1)
+    assert ((geometric * stored).sum(axis=1) > 0).all()
+    constants = oracle.write_constants(cornell_spec, 64, 64, cornell, cornell_lights)
+    triangles, _, front = oracle_cornell.primary_hits(constants, 2696)
+    assert front[triangles >= 0].all()
+
+
+def test_elementary_functions():
+    xs = np.linspace(-4.0, 7.0, 4001).astype(np.float32)
+    for x in xs:
+        s, c = oracle.sincos(float(x))
+        assert abs(s - np.sin(np.float64(x))) < 3e-7 and abs(c - np.cos(np.float64(x))) < 3e-7
+    for x in np.concatenate([np.geomspace(1e-37, 1e30, 500), [1.0, 0.5, 2.0]]).astype(np.float32):
+        assert abs(oracle.log(float(x)) - np.log(np.float64(x))) <= 2e-7 * max(1.0, abs(np.log(np.float64(x))))
+    for x in np.linspace(-0.9999, 0.9999, 801).astype(np.float32):
+        expected = scipy.special.erfinv(np.float64(x))
+        # 1 - x * x cancels in single precision near the ends (that is the reference's formula), hence the looser bound
+        tolerance = 2e-6 if abs(x) <= 0.99 else 1e-4
+        assert abs(oracle.erfinv(float(x)) - expected) <= tolerance * max(1.0, abs(expected))
+
+
+def test_invert_mat4_and_camera(cornell, cornell_lights, cornell_spec):
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        m = rng.normal(size=(4, 4)).astype(np.float32)
+        inv = oracle.invert_mat4(m)
+        np.testing.assert_allclose(inv.astype(np.float64) @ m.astype(np.float64), np.eye(4), atol=2e-3)
+    constants = oracle.write_constants(cornell_spec, 512, 512, cornell, cornell_lights)
+    w2p = np.array(constants.world_to_projection_space, np.float64).reshape(4, 4)
+    p2w = np.array(constants.projection_to_world_space, np.float64).reshape(4, 4)
+    np.testing.assert_allclose(w2p @ p2w, np.eye(4), atol=1e-5)
+    assert constants.accum_frame_count == 1 and constants.frame_index == 2695
+    assert tuple(constants.viewport_size) == (512.0, 512.0)
+    assert tuple(constants.emission_material_radiance) == (20.0, np.float32(0.9) * np.float32(20.0), np.float32(0.6) * np.float32(20.0))
+    # the camera looks along -y from y = 0.379: the hemispherical camera normal is row 2 of world to view
+    np.testing.assert_allclose(tuple(constants.hemispherical_camera_normal), (0, 1, 0), atol=1e-6)
+
+
+# ---- block decoding against an independent numpy decoder ----
+
+def bc1_texel(block, px, py):
+    c0, c1 = int.from_bytes(block[0:2], "little"), int.from_bytes(block[2:4], "little")
+    bits = int.from_bytes(block[4:8], "little")
+    code = (bits >> (2 * (4 * py + px))) & 3
+
+    def expand(c):
+        r, g, b = (c >> 11) & 31, (c >> 5) & 63, c & 31
+        return np.array([(r << 3) | (r >> 2), (g << 2) | (g >> 4), (b << 3) | (b >> 2)])
+    e0, e1 = expand(c0), expand(c1)
+    if code == 0:
+        return e0
+    if code == 1:
+        return e1
+    if c0 > c1:
+        return (2 * e0 + e1) // 3 if code == 2 else (e0 + 2 * e1) // 3
+    return (e0 + e1) // 2 if code == 2 else np.zeros(3, int)
+
+
+def bc4_texel(block, px, py):
+    a0, a1 = block[0], block[1]
+    bits = int.from_bytes(block[2:8], "little")
+    code = (bits >> (3 * (4 * py + px))) & 7
+    if a0 > a1:
+        palette = [a0, a1] + [((7 - i) * a0 + i * a1) // 7 for i in range(1, 7)]
+    else:
+        palette = [a0, a1] + [((5 - i) * a0 + i * a1) // 5 for i in range(1, 5)] + [0, 255]
+    return palette[code]
+
+
+def srgb_to_linear(c):
+    c = c / 255.0
+    return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+
+
+@pytest.mark.parametrize("fmt", [131, 132, 141])
+def test_block_decode_at_texel_centers(fmt):
+    rng = np.random.default_rng(fmt)
+    size = 16
+    block_bytes = 16 if fmt == 141 else 8
+    payload = rng.integers(0, 256, (size // 4) * (size // 4) * block_bytes, dtype=np.uint8)
+    texture = formats.Texture(size, size, fmt, 1, [(size, size, len(payload))], np.array([0], np.uint64), payload)
+    scene = formats.Scene(["m"], 0, np.ones(3, np.float32), np.zeros(3, np.float32), np.zeros((0, 2), np.uint32), np.zeros((0, 4), np.uint16), np.zeros(0, np.uint8), [texture] * 3)
+    s = oracle.OracleScene(scene)
+    ys, xs = np.mgrid[0:size, 0:size]
+    uvs = np.stack([(xs + 0.5) / size, (ys + 0.5) / size], -1).reshape(-1, 2)
+    got = s.sample_texture(0, uvs).reshape(size, size, 3)
+    for y in range(size):
+        for x in range(size):
+            block = bytes(payload[((y // 4) * (size // 4) + x // 4) * block_bytes:][:block_bytes])
+            if fmt == 141:
+                expected = np.array([bc4_texel(block[:8], x & 3, y & 3), bc4_texel(block[8:], x & 3, y & 3), 0]) / 255.0
+            else:
+                rgb = bc1_texel(block, x & 3, y & 3)
+                expected = srgb_to_linear(rgb) if fmt == 132 else rgb / 255.0
+            np.testing.assert_allclose(got[y, x], expected, atol=1e-6)
+
+
+def test_bilinear_filtering_and_repeat():
+    # a 4x4 BC1 texture with two colours: left half code 0, right half code 1
+    c0, c1 = 0xf800, 0x001f
+    codes = 0
+    for py in range(4):
+        for px in range(4):
+            codes |= (0 if px < 2 else 1) << (2 * (4 * py + px))
+    payload = np.frombuffer(c0.to_bytes(2, "little") + c1.to_bytes(2, "little") + codes.to_bytes(4, "little"), np.uint8)
+    texture = formats.Texture(4, 4, 131, 1, [(4, 4, 8)], np.array([0], np.uint64), payload)
+    scene = formats.Scene(["m"], 0, np.ones(3, np.float32), np.zeros(3, np.float32), np.zeros((0, 2), np.uint32), np.zeros((0, 4), np.uint16), np.zeros(0, np.uint8), [texture] * 3)
+    s = oracle.OracleScene(scene)
+    # halfway between texel 1 (red) and texel 2 (blue)
+    np.testing.assert_allclose(s.sample_texture(0, [[0.5, 0.5]])[0], [0.5, 0, 0.5], atol=1e-6)
+    # REPEAT: u = 0 lies halfway between texel 3 (blue) and texel 0 (red); u + 1 and u - 3 are the same place
+    np.testing.assert_allclose(s.sample_texture(0, [[0.0, 0.5]])[0], [0.5, 0, 0.5], atol=1e-6)
+    a = s.sample_texture(0, [[0.3, 0.2], [1.3, 0.2], [-2.7, 1.2]])
+    np.testing.assert_allclose(a[0], a[1], atol=1e-6)
+    np.testing.assert_allclose(a[0], a[2], atol=2e-6)
+
+
+def test_estimators_agree(cornell, cornell_lights, cornell_spec, oracle_cornell):
+    """The four sampling strategies estimate the same integral (pathtrace.frag.glsl:224,258,286,315)."""
+    constants = oracle.write_constants(cornell_spec, 24, 24, cornell, cornell_lights)
+    means = []
+    for strategy in (1, 2, 3):
+        image, _ = oracle_cornell.render(constants, cornell_lights, strategy=strategy, path_length=3, first_frame_index=1, frame_count=600, threads=8)
+        means.append(image[..., :3].mean(axis=(0, 1)) / 600)
+    for m in means[:-1]:
+        np.testing.assert_allclose(m, means[-1], rtol=0.08)
+
+
+def test_path_length_semantics(cornell, cornell_lights, cornell_spec, oracle_cornell):
+    constants = oracle.write_constants(cornell_spec, 32, 32, cornell, cornell_lights)
+    black, rays = oracle_cornell.render(constants, cornell_lights, path_length=0, first_frame_index=5, frame_count=2)
+    assert rays == 0 and (black[..., :3] == 0).all() and (black[..., 3] == 1).all()
+    emission_only, rays = oracle_cornell.render(constants, cornell_lights, path_length=1, first_frame_index=5, frame_count=1)
+    assert rays == 32 * 32
+    colours = np.unique(emission_only[..., :3].reshape(-1, 3), axis=0)
+    assert len(colours) == 2 and (colours[0] == 0).all()
+    np.testing.assert_allclose(colours[1], [20.0, 18.0, 12.0], rtol=1e-6)

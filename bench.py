@@ -49,7 +49,7 @@ def cpu_baseline(args, threads):
     scene = formats.load_scene(os.path.join(data, "cornell_box.vks"), os.path.join(data, "cornell_box_textures"))
     lights = formats.load_lights(os.path.join(data, "cornell_box.lights"))
     spec = formats.load_rt_save(os.path.join(data, "saves", "cornell_box", "default.rt_save"))
-    width, height, spp = args.width // 4, args.height // 4, 8
+    width, height, spp = args.width // 2, args.height // 2, 16
     constants = oracle.write_constants(spec, width, height, scene, lights)
     cpu_scene = oracle.OracleScene(scene)
     begin = time.perf_counter()

@@ -165,7 +165,7 @@ struct PtTraceArgs {
 };
 
 // pathtrace.frag.glsl:365-386 for every path of the batch
-__global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtConstants* constants, PtWavefront wf, uint32_t path_count) {
+__global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtConstants* constants, PtWavefront wf, uint32_t path_count, uint32_t ray_count) {
 	uint32_t p = blockIdx.x * PT_BLOCK + threadIdx.x;
 	if (p >= path_count)
 		return;
@@ -180,8 +180,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtCons
 	wf.state0[p] = mk4(1.0f, 1.0f, 1.0f, pt_as_float(sx));
 	wf.state1[p] = mk4(1.0f, 1.0f, 1.0f, pt_as_float(sy));
 	wf.radiance[p] = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+	// ray_count is path_count, or 0 when the path length is 0 and no ray is ever traced
 	if (p == 0)
-		wf.ext_count[0] = path_count;
+		wf.ext_count[0] = ray_count;
 }
 
 // trace_ray() of pathtrace.frag.glsl:181-199 up to the hit record
@@ -451,7 +452,10 @@ struct pt_scene {
 	struct timed_launch { int kind; hipEvent_t begin, end; };
 	std::vector<timed_launch> pending_events;
 	std::vector<hipEvent_t> event_pool;
-	std::vector<uint32_t*> pending_counter_reads;
+	// queue size snapshots of finished batches and the number of padding
+	// paths (outside the image) that each of them carried in its first queue
+	struct counter_read { uint32_t* counters; uint32_t padding_paths; };
+	std::vector<counter_read> pending_counter_reads;
 };
 
 #define PT_COUNTER_WORDS (2 * (PT_MAX_PATH_LENGTH + 1))
@@ -527,7 +531,9 @@ static void pt_collect(pt_scene* s) {
 	}
 	s->pending_events.clear();
 	for (size_t i = 0; i != s->pending_counter_reads.size(); ++i) {
-		uint32_t* c = s->pending_counter_reads[i];
+		uint32_t* c = s->pending_counter_reads[i].counters;
+		if (c[0] >= s->pending_counter_reads[i].padding_paths)
+			s->stats.extension_rays -= s->pending_counter_reads[i].padding_paths;
 		for (uint32_t k = 0; k <= PT_MAX_PATH_LENGTH; ++k) {
 			s->stats.extension_rays += c[k];
 			s->stats.shadow_rays += c[PT_MAX_PATH_LENGTH + 1 + k];
@@ -929,7 +935,7 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 	PT_CHECK(hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * PT_COUNTER_WORDS, s->stream));
 	{
 		pt_launch_timer timer(s, PT_K_RAYGEN);
-		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count);
+		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count, s->path_length ? path_count : 0u);
 	}
 	uint32_t parity = 0;
 	for (uint32_t k = 1; k <= s->path_length; ++k) {
@@ -965,7 +971,8 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 	uint32_t* snapshot = NULL;
 	PT_CHECK(hipHostMalloc((void**) &snapshot, sizeof(uint32_t) * PT_COUNTER_WORDS, hipHostMallocDefault));
 	PT_CHECK(hipMemcpyAsync(snapshot, s->counters, sizeof(uint32_t) * PT_COUNTER_WORDS, hipMemcpyDeviceToHost, s->stream));
-	s->pending_counter_reads.push_back(snapshot);
+	pt_scene::counter_read read = { snapshot, path_count - s->width * s->height * frame_count };
+	s->pending_counter_reads.push_back(read);
 	s->stats.paths += (uint64_t) s->width * s->height * frame_count;
 	PT_CHECK(hipGetLastError());
 	return 0;
@@ -1120,7 +1127,7 @@ extern "C" int pt_trace_primary_rays(pt_scene_t* s, const pt_constants_t* consta
 		if (hipMemcpyAsync(s->constants, constants, sizeof(PtConstants), hipMemcpyHostToDevice, s->stream) != hipSuccess
 			|| hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * PT_COUNTER_WORDS, s->stream) != hipSuccess)
 			break;
-		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count);
+		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count, path_count);
 		PtTraceArgs a = pt_trace_args(s, 0, 0);
 		hipLaunchKernelGGL(k_trace_extension<false>, dim3(pt_grid_chunked(path_count)), dim3(PT_BLOCK), 0, s->stream, a);
 		hipLaunchKernelGGL(k_gather_primary_hits, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->wf, d_triangles, d_barycentrics, d_front);

@@ -61,6 +61,9 @@ def cpu_baseline(args, threads):
 
 def main():
     args = parse_args()
+    # The C host reports progress on stdout like the reference does; keep stdout for the one JSON line
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -168,7 +171,8 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, min(16, os.cpu_count() or 1))
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result), flush=True)
+        C.CDLL(None).fflush(None)
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     renderer.close()
     if world_size > 1:
         dist.destroy_process_group()

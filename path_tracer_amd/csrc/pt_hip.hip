@@ -15,6 +15,7 @@
 #include "pt_bvh_build.h"
 #include "pt_trace.h"
 #include "pt_shade.h"
+#include "pt_trace_wave.h"
 #include "../../include/pt_hip.h"
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -25,7 +26,6 @@
 static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device constants must agree");
 
 #define PT_BLOCK 256
-#define PT_LDS_STACK 12
 #define PT_INVALID 0xffffffffu
 
 #define PT_CHECK(call) do { hipError_t pt_err_ = (call); if (pt_err_ != hipSuccess) { \
@@ -129,30 +129,6 @@ __device__ __forceinline__ uint32_t pt_wave_push(uint32_t* counter, bool want) {
 	return base + prefix;
 }
 
-// Short traversal stack: the first PT_LDS_STACK entries of every lane live
-// in LDS (entry-major, so a wave's accesses are consecutive 8-byte words),
-// deeper entries in a global overflow buffer laid out the same way.
-struct PtGpuStack {
-	u32x2* lds;
-	u32x2* overflow;
-	uint32_t overflow_stride, capacity;
-	uint32_t sp;
-	__device__ __forceinline__ void push(u32x2 e) {
-		if (sp < PT_LDS_STACK)
-			lds[sp * PT_BLOCK] = e;
-		else if (sp < capacity)
-			overflow[(uint64_t) (sp - PT_LDS_STACK) * overflow_stride] = e;
-		else
-			return;
-		++sp;
-	}
-	__device__ __forceinline__ u32x2 pop() {
-		--sp;
-		return (sp < PT_LDS_STACK) ? lds[sp * PT_BLOCK] : overflow[(uint64_t) (sp - PT_LDS_STACK) * overflow_stride];
-	}
-	__device__ __forceinline__ bool empty() const { return sp == 0; }
-};
-
 struct PtTraceArgs {
 	PtSceneView scene;
 	PtWavefront wf;
@@ -161,6 +137,8 @@ struct PtTraceArgs {
 	uint32_t stack_overflow_stride, stack_capacity;
 	uint32_t bounce;  // index into ext_count / shadow_count
 	uint32_t parity;  // which ray queue holds this bounce
+	uint32_t* fetch;  // 8 zeroed fetch counters for this launch
+	PtCacheLayout cache_layout;
 	unsigned long long* visit_counters; // nodes, triangles of extension rays [0], [1] and of shadow rays [2], [3], or NULL
 };
 
@@ -185,81 +163,57 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtCons
 		wf.ext_count[0] = ray_count;
 }
 
-// trace_ray() of pathtrace.frag.glsl:181-199 up to the hit record
+// trace_ray() of pathtrace.frag.glsl:181-199 up to the hit record.
+// Persistent waves: the grid is sized to the chip, not to the queue.
 template <bool COUNT_VISITS>
-__global__ void __launch_bounds__(PT_BLOCK) k_trace_extension(PtTraceArgs a) {
-	__shared__ u32x2 lds_stack[PT_LDS_STACK * PT_BLOCK];
-	uint32_t first_slot;
-	uint32_t count = a.wf.ext_count[a.bounce];
-	if (!pt_block_first_slot(count, &first_slot))
-		return;
-	uint32_t slot = first_slot + threadIdx.x;
-	if (slot >= count)
-		return;
-	f32x4 o = a.wf.ray_o[a.parity][slot], d = a.wf.ray_d[a.parity][slot];
-	PtHit hit;
-	hit.prim = PT_INVALID;
-	hit.t = 1e38f;
-	hit.u = hit.v = 0.0f;
-	hit.front = false;
-	if (pt_as_uint(o.w) != PT_INVALID) {
-		PtGpuStack stack;
-		stack.lds = &lds_stack[threadIdx.x];
-		stack.overflow = a.stack_overflow + (blockIdx.x * PT_BLOCK + threadIdx.x);
-		stack.overflow_stride = a.stack_overflow_stride;
-		stack.capacity = a.stack_capacity;
-		stack.sp = 0;
-		uint32_t visits[2] = { 0, 0 };
-		hit = pt_trace_closest<COUNT_VISITS>(a.scene.nodes, a.scene.tris, a.scene.triangle_count, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 1.0e-3f, 1e38f, stack, visits);
-		if (COUNT_VISITS) {
-			atomicAdd(&a.visit_counters[0], (unsigned long long) visits[0]);
-			atomicAdd(&a.visit_counters[1], (unsigned long long) visits[1]);
-		}
-	}
-	u32x4 record;
-	record.x = hit.prim;
-	record.y = pt_as_uint(hit.u);
-	record.z = pt_as_uint(hit.v);
-	record.w = hit.front ? 1u : 0u;
-	a.wf.hit[slot] = record;
+__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_extension(PtTraceArgs a) {
+	__shared__ PtTraceLds lds;
+	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
+	PtRayQueue queue;
+	queue.origin = a.wf.ray_o[a.parity];
+	queue.direction = a.wf.ray_d[a.parity];
+	queue.count = &a.wf.ext_count[a.bounce];
+	queue.fetch = a.fetch;
+	u32x4* hits = a.wf.hit;
+	pt_trace_wave<COUNT_VISITS>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
+		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters,
+		[&](uint32_t slot, float, float, const PtHit& hit) {
+			u32x4 record;
+			record.x = hit.prim;
+			record.y = pt_as_uint(hit.u);
+			record.z = pt_as_uint(hit.v);
+			record.w = hit.front ? 1u : 0u;
+			hits[slot] = record;
+		});
 }
 
 // trace_ray_emission() of pathtrace.frag.glsl:203-219 and the MIS sum at :338
 template <bool COUNT_VISITS>
-__global__ void __launch_bounds__(PT_BLOCK) k_trace_shadow(PtTraceArgs a) {
-	__shared__ u32x2 lds_stack[PT_LDS_STACK * PT_BLOCK];
-	uint32_t first_slot;
-	uint32_t count = a.wf.shadow_count[a.bounce];
-	if (!pt_block_first_slot(count, &first_slot))
-		return;
-	uint32_t slot = first_slot + threadIdx.x;
-	if (slot >= count)
-		return;
-	f32x4 o = a.wf.sh_o[slot], d = a.wf.sh_d[slot], w = a.wf.sh_w[slot];
-	PtGpuStack stack;
-	stack.lds = &lds_stack[threadIdx.x];
-	stack.overflow = a.stack_overflow + (blockIdx.x * PT_BLOCK + threadIdx.x);
-	stack.overflow_stride = a.stack_overflow_stride;
-	stack.capacity = a.stack_capacity;
-	stack.sp = 0;
-	uint32_t visits[2] = { 0, 0 };
-	PtHit hit = pt_trace_closest<COUNT_VISITS>(a.scene.nodes, a.scene.tris, a.scene.triangle_count, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), 1.0e-3f, 1e38f, stack, visits);
-	if (COUNT_VISITS) {
-		atomicAdd(&a.visit_counters[2], (unsigned long long) visits[0]);
-		atomicAdd(&a.visit_counters[3], (unsigned long long) visits[1]);
-	}
-	const PtConstants& c = *a.constants;
-	v3 emission;
-	if (hit.prim == PT_INVALID)
-		emission = mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
-	else if (a.scene.materials[hit.prim] == a.scene.emission_material_index)
-		emission = mk3(c.emission_material_radiance[0], c.emission_material_radiance[1], c.emission_material_radiance[2]);
-	else
-		emission = mk3(0.0f, 0.0f, 0.0f);
-	uint32_t path = pt_as_uint(o.w);
-	f32x4 radiance = a.wf.radiance[path];
-	v3 sum = mk3(radiance.x, radiance.y, radiance.z) + (mk3(w.x, w.y, w.z) * emission) * d.w;
-	a.wf.radiance[path] = mk4(sum.x, sum.y, sum.z, 0.0f);
+__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_shadow(PtTraceArgs a) {
+	__shared__ PtTraceLds lds;
+	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
+	PtRayQueue queue;
+	queue.origin = a.wf.sh_o;
+	queue.direction = a.wf.sh_d;
+	queue.count = &a.wf.shadow_count[a.bounce];
+	queue.fetch = a.fetch;
+	pt_trace_wave<COUNT_VISITS>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
+		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters ? a.visit_counters + 2 : NULL,
+		[&](uint32_t slot, float path_bits, float factor, const PtHit& hit) {
+			const PtConstants& c = *a.constants;
+			v3 emission;
+			if (hit.prim == PT_INVALID)
+				emission = mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
+			else if (a.scene.materials[hit.prim] == a.scene.emission_material_index)
+				emission = mk3(c.emission_material_radiance[0], c.emission_material_radiance[1], c.emission_material_radiance[2]);
+			else
+				emission = mk3(0.0f, 0.0f, 0.0f);
+			f32x4 w = a.wf.sh_w[slot];
+			uint32_t path = pt_as_uint(path_bits);
+			f32x4 radiance = a.wf.radiance[path];
+			v3 sum = mk3(radiance.x, radiance.y, radiance.z) + (mk3(w.x, w.y, w.z) * emission) * factor;
+			a.wf.radiance[path] = mk4(sum.x, sum.y, sum.z, 0.0f);
+		});
 }
 
 struct PtShadeArgs {
@@ -360,24 +314,37 @@ __global__ void __launch_bounds__(PT_BLOCK) k_gather_primary_hits(PtBatch batch,
 	front[pixel] = (uint8_t) hit.w;
 }
 
-__global__ void __launch_bounds__(PT_BLOCK) k_trace_user_rays(PtTraceArgs a, const float* origins, const float* directions, uint32_t count, int32_t* triangles, float* t_u_v, uint8_t* front) {
-	__shared__ u32x2 lds_stack[PT_LDS_STACK * PT_BLOCK];
-	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
-	if (i >= count)
-		return;
-	PtGpuStack stack;
-	stack.lds = &lds_stack[threadIdx.x];
-	stack.overflow = a.stack_overflow + i;
-	stack.overflow_stride = a.stack_overflow_stride;
-	stack.capacity = a.stack_capacity;
-	stack.sp = 0;
-	PtHit hit = pt_trace_closest<false>(a.scene.nodes, a.scene.tris, a.scene.triangle_count,
-		mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), mk3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]), 1.0e-3f, 1e38f, stack, NULL);
-	triangles[i] = (int32_t) hit.prim;
-	t_u_v[3 * i] = hit.t;
-	t_u_v[3 * i + 1] = hit.u;
-	t_u_v[3 * i + 2] = hit.v;
-	front[i] = hit.front ? 1 : 0;
+struct PtUserRayArgs {
+	PtSceneView scene;
+	const f32x4* origins;
+	const f32x4* directions;
+	const uint32_t* count;
+	uint32_t* fetch;
+	u32x2* stack_overflow;
+	uint32_t stack_overflow_stride, stack_capacity;
+	PtCacheLayout cache_layout;
+	int32_t* triangles;
+	float* t_u_v;
+	uint8_t* front;
+};
+
+__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_user_rays(PtUserRayArgs a) {
+	__shared__ PtTraceLds lds;
+	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
+	PtRayQueue queue;
+	queue.origin = a.origins;
+	queue.direction = a.directions;
+	queue.count = a.count;
+	queue.fetch = a.fetch;
+	pt_trace_wave<false>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
+		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, NULL,
+		[&](uint32_t slot, float, float, const PtHit& hit) {
+			a.triangles[slot] = (int32_t) hit.prim;
+			a.t_u_v[3 * slot] = hit.t;
+			a.t_u_v[3 * slot + 1] = hit.u;
+			a.t_u_v[3 * slot + 2] = hit.v;
+			a.front[slot] = hit.front ? 1 : 0;
+		});
 }
 
 __global__ void __launch_bounds__(PT_BLOCK) k_shading_data(PtSceneView scene, const PtConstants* constants, const int32_t* triangles, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out) {
@@ -443,6 +410,7 @@ struct pt_scene {
 	PtConstants* constants;
 	u32x2* stack_overflow;
 	uint32_t stack_capacity, stack_overflow_stride;
+	uint32_t trace_grid; // blocks of the persistent traversal kernels
 	unsigned long long* visit_counters;
 	// pinned host staging for counter readback
 	uint32_t* host_counters;
@@ -458,7 +426,9 @@ struct pt_scene {
 	std::vector<counter_read> pending_counter_reads;
 };
 
+// ext_count[k] and shadow_count[k] per bounce, then 8 fetch counters for each of the possible trace launches of a batch
 #define PT_COUNTER_WORDS (2 * (PT_MAX_PATH_LENGTH + 1))
+#define PT_FETCH_WORDS (8 * PT_FETCH_STRIDE * PT_COUNTER_WORDS)
 
 static uint32_t pt_grid(uint64_t count) { return (uint32_t) ((count + PT_BLOCK - 1) / PT_BLOCK); }
 // Grid for kernels that use pt_block_first_slot(): a multiple of 8 blocks
@@ -563,7 +533,6 @@ static void pt_free_render_targets(pt_scene* s) {
 	hipFree(s->wf.state0); s->wf.state0 = NULL;
 	hipFree(s->wf.state1); s->wf.state1 = NULL;
 	hipFree(s->wf.radiance); s->wf.radiance = NULL;
-	hipFree(s->stack_overflow); s->stack_overflow = NULL;
 	s->capacity = 0;
 	s->width = s->height = 0;
 }
@@ -585,12 +554,6 @@ static int pt_reserve_wavefront(pt_scene* s, uint32_t path_count) {
 	}
 	if (pt_alloc(&s->wf.hit, path_count) || pt_alloc(&s->wf.sh_o, path_count) || pt_alloc(&s->wf.sh_d, path_count) || pt_alloc(&s->wf.sh_w, path_count)
 		|| pt_alloc(&s->wf.state0, path_count) || pt_alloc(&s->wf.state1, path_count) || pt_alloc(&s->wf.radiance, path_count))
-		return 1;
-	s->stack_capacity = s->bvh_info.depth + 2;
-	if (s->stack_capacity < PT_LDS_STACK + 1)
-		s->stack_capacity = PT_LDS_STACK + 1;
-	s->stack_overflow_stride = pt_grid_chunked(path_count) * PT_BLOCK;
-	if (pt_alloc(&s->stack_overflow, (uint64_t) s->stack_overflow_stride * (s->stack_capacity - PT_LDS_STACK)))
 		return 1;
 	s->capacity = path_count;
 	return 0;
@@ -755,7 +718,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 	s->sample_count = 0;
 	memset(&s->wf, 0, sizeof(s->wf));
 	s->counters = NULL; s->constants = NULL; s->stack_overflow = NULL; s->visit_counters = NULL; s->host_counters = NULL;
-	s->stack_capacity = s->stack_overflow_stride = 0;
+	s->stack_capacity = s->stack_overflow_stride = s->trace_grid = 0;
 	s->timing_enabled = s->visit_counters_enabled = 0;
 	memset(&s->stats, 0, sizeof(s->stats));
 	int failed = 1;
@@ -764,7 +727,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 			break;
 		uint64_t n = s->triangle_count;
 		if (pt_alloc(&s->positions, 3 * n) || pt_alloc(&s->normals_uvs, 3 * n) || pt_alloc(&s->materials, n)
-			|| pt_alloc(&s->counters, PT_COUNTER_WORDS) || pt_alloc(&s->constants, 1) || pt_alloc(&s->visit_counters, 8)
+			|| pt_alloc(&s->counters, PT_COUNTER_WORDS + PT_FETCH_WORDS) || pt_alloc(&s->constants, 1) || pt_alloc(&s->visit_counters, 16)
 			|| pt_alloc(&s->srgb_to_linear, 256) || pt_alloc(&s->lights, 1))
 			break;
 		if (n) {
@@ -773,7 +736,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 				|| hipMemcpyAsync(s->materials, material_indices, n, hipMemcpyHostToDevice, s->stream) != hipSuccess)
 				break;
 		}
-		if (hipMemsetAsync(s->visit_counters, 0, 8 * sizeof(unsigned long long), s->stream) != hipSuccess)
+		if (hipMemsetAsync(s->visit_counters, 0, 16 * sizeof(unsigned long long), s->stream) != hipSuccess)
 			break;
 		// sRGB decoding table for VK_FORMAT_BC1_RGB_SRGB_BLOCK textures
 		float table[256];
@@ -809,6 +772,17 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 			break;
 		if (pt_build_bvh(s, header))
 			break;
+		// The traversal kernels are persistent: one workgroup of sixteen waves per CU
+		int cu_count = 0;
+		if (hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, device_index) != hipSuccess || cu_count <= 0)
+			break;
+		s->trace_grid = ((uint32_t) cu_count + 7) & ~7u;
+		s->stack_capacity = s->bvh_info.depth + 2;
+		if (s->stack_capacity < PT_WAVE_STACK + 1)
+			s->stack_capacity = PT_WAVE_STACK + 1;
+		s->stack_overflow_stride = s->trace_grid * PT_TRACE_BLOCK;
+		if (pt_alloc(&s->stack_overflow, (uint64_t) s->stack_overflow_stride * (s->stack_capacity - PT_WAVE_STACK)))
+			break;
 		failed = 0;
 	} while (0);
 	if (failed) {
@@ -832,7 +806,7 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 	pt_free_render_targets(s);
 	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->materials); hipFree(s->textures); hipFree(s->texture_blob);
 	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->nodes); hipFree(s->tris);
-	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters);
+	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters); hipFree(s->stack_overflow);
 	if (s->stream)
 		hipStreamDestroy(s->stream);
 	delete s;
@@ -900,7 +874,7 @@ extern "C" int pt_create_render_targets(pt_scene_t* s, uint32_t width, uint32_t 
 	return 0;
 }
 
-static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity) {
+static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity, bool shadow) {
 	PtTraceArgs a;
 	a.scene = pt_scene_view(s);
 	a.wf = s->wf;
@@ -910,17 +884,19 @@ static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity) 
 	a.stack_capacity = s->stack_capacity;
 	a.bounce = bounce;
 	a.parity = parity;
+	a.cache_layout = pt_cache_layout(s->bvh_info.node_count, s->bvh_info.triangle_count);
+	a.fetch = s->counters + PT_COUNTER_WORDS + 8 * PT_FETCH_STRIDE * (shadow ? PT_MAX_PATH_LENGTH + 1 + bounce : bounce);
 	a.visit_counters = s->visit_counters_enabled ? s->visit_counters : NULL;
 	return a;
 }
 
 static void pt_launch_trace_extension(pt_scene* s, uint32_t bounce, uint32_t parity, uint32_t capacity) {
 	pt_launch_timer timer(s, PT_K_TRACE_EXT);
-	PtTraceArgs a = pt_trace_args(s, bounce, parity);
+	PtTraceArgs a = pt_trace_args(s, bounce, parity, false);
 	if (s->visit_counters_enabled)
-		hipLaunchKernelGGL(k_trace_extension<true>, dim3(pt_grid_chunked(capacity)), dim3(PT_BLOCK), 0, s->stream, a);
+		hipLaunchKernelGGL(k_trace_extension<true>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 	else
-		hipLaunchKernelGGL(k_trace_extension<false>, dim3(pt_grid_chunked(capacity)), dim3(PT_BLOCK), 0, s->stream, a);
+		hipLaunchKernelGGL(k_trace_extension<false>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 }
 
 // Renders one batch of frame_count frames
@@ -932,7 +908,7 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 	uint32_t path_count = batch.paths_per_frame * frame_count;
 	s->wf.ext_count = s->counters;
 	s->wf.shadow_count = s->counters + PT_MAX_PATH_LENGTH + 1;
-	PT_CHECK(hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * PT_COUNTER_WORDS, s->stream));
+	PT_CHECK(hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * (PT_COUNTER_WORDS + PT_FETCH_WORDS), s->stream));
 	{
 		pt_launch_timer timer(s, PT_K_RAYGEN);
 		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count, s->path_length ? path_count : 0u);
@@ -955,11 +931,11 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 		}
 		if (s->strategy == PT_STRATEGY_NEE && k < s->path_length) {
 			pt_launch_timer timer(s, PT_K_TRACE_SHADOW);
-			PtTraceArgs a = pt_trace_args(s, k, 0);
+			PtTraceArgs a = pt_trace_args(s, k, 0, true);
 			if (s->visit_counters_enabled)
-				hipLaunchKernelGGL(k_trace_shadow<true>, dim3(pt_grid_chunked(path_count)), dim3(PT_BLOCK), 0, s->stream, a);
+				hipLaunchKernelGGL(k_trace_shadow<true>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 			else
-				hipLaunchKernelGGL(k_trace_shadow<false>, dim3(pt_grid_chunked(path_count)), dim3(PT_BLOCK), 0, s->stream, a);
+				hipLaunchKernelGGL(k_trace_shadow<false>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 		}
 		parity ^= 1;
 	}
@@ -1069,13 +1045,15 @@ extern "C" int pt_get_statistics(pt_scene_t* s, pt_statistics_t* out) {
 		return 1;
 	if (pt_synchronize(s))
 		return 1;
-	unsigned long long visits[8];
+	unsigned long long visits[16];
 	PT_CHECK(hipMemcpy(visits, s->visit_counters, sizeof(visits), hipMemcpyDeviceToHost));
 	s->stats.nodes_visited[0] = visits[0];
 	s->stats.triangles_tested[0] = visits[1];
 	s->stats.nodes_visited[1] = visits[2];
 	s->stats.triangles_tested[1] = visits[3];
 	s->stats.shaded_hits = visits[4];
+	if (getenv("PT_TRACE_DIAGNOSTICS"))
+		printf("trace diagnostics: extension passes %llu active-lane-passes %llu refills %llu; shadow passes %llu active-lane-passes %llu refills %llu\n", visits[6], visits[7], visits[10], visits[8], visits[9], visits[12]);
 	*out = s->stats;
 	return 0;
 }
@@ -1086,7 +1064,7 @@ extern "C" int pt_reset_statistics(pt_scene_t* s) {
 	if (pt_synchronize(s))
 		return 1;
 	memset(&s->stats, 0, sizeof(s->stats));
-	PT_CHECK(hipMemset(s->visit_counters, 0, 8 * sizeof(unsigned long long)));
+	PT_CHECK(hipMemset(s->visit_counters, 0, 16 * sizeof(unsigned long long)));
 	return 0;
 }
 
@@ -1125,11 +1103,11 @@ extern "C" int pt_trace_primary_rays(pt_scene_t* s, const pt_constants_t* consta
 		s->wf.ext_count = s->counters;
 		s->wf.shadow_count = s->counters + PT_MAX_PATH_LENGTH + 1;
 		if (hipMemcpyAsync(s->constants, constants, sizeof(PtConstants), hipMemcpyHostToDevice, s->stream) != hipSuccess
-			|| hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * PT_COUNTER_WORDS, s->stream) != hipSuccess)
+			|| hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * (PT_COUNTER_WORDS + PT_FETCH_WORDS), s->stream) != hipSuccess)
 			break;
 		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count, path_count);
-		PtTraceArgs a = pt_trace_args(s, 0, 0);
-		hipLaunchKernelGGL(k_trace_extension<false>, dim3(pt_grid_chunked(path_count)), dim3(PT_BLOCK), 0, s->stream, a);
+		PtTraceArgs a = pt_trace_args(s, 0, 0, false);
+		hipLaunchKernelGGL(k_trace_extension<false>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 		hipLaunchKernelGGL(k_gather_primary_hits, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->wf, d_triangles, d_barycentrics, d_front);
 		if (hipMemcpyAsync(triangle_indices, d_triangles, pixels * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess
 			|| hipMemcpyAsync(barycentrics, d_barycentrics, 2 * pixels * sizeof(float), hipMemcpyDeviceToHost, s->stream) != hipSuccess
@@ -1153,24 +1131,39 @@ extern "C" int pt_trace_rays(pt_scene_t* s, const float* origins, const float* d
 		return 0;
 	PT_CHECK(hipSetDevice(s->device));
 	PT_CHECK(hipStreamSynchronize(s->stream));
-	float* d_origins = NULL; float* d_directions = NULL; int32_t* d_triangles = NULL; float* d_tuv = NULL; uint8_t* d_front = NULL;
-	u32x2* overflow = NULL;
+	f32x4* d_origins = NULL; f32x4* d_directions = NULL; int32_t* d_triangles = NULL; float* d_tuv = NULL; uint8_t* d_front = NULL;
+	uint32_t* d_control = NULL; // ray count followed by 8 fetch counters
+	std::vector<f32x4> staging(2 * (size_t) ray_count);
+	for (uint32_t i = 0; i != ray_count; ++i) {
+		staging[i] = mk4(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2], pt_as_float(i));
+		staging[ray_count + i] = mk4(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2], 0.0f);
+	}
 	int result = 1;
 	do {
-		uint32_t stack_capacity = s->bvh_info.depth + 2;
-		if (stack_capacity < PT_LDS_STACK + 1) stack_capacity = PT_LDS_STACK + 1;
-		uint32_t stride = pt_grid(ray_count) * PT_BLOCK;
-		if (pt_alloc(&d_origins, 3 * (uint64_t) ray_count) || pt_alloc(&d_directions, 3 * (uint64_t) ray_count) || pt_alloc(&d_triangles, ray_count)
-			|| pt_alloc(&d_tuv, 3 * (uint64_t) ray_count) || pt_alloc(&d_front, ray_count) || pt_alloc(&overflow, (uint64_t) stride * (stack_capacity - PT_LDS_STACK)))
+		if (pt_alloc(&d_origins, ray_count) || pt_alloc(&d_directions, ray_count) || pt_alloc(&d_triangles, ray_count)
+			|| pt_alloc(&d_tuv, 3 * (uint64_t) ray_count) || pt_alloc(&d_front, ray_count) || pt_alloc(&d_control, 1 + 8 * PT_FETCH_STRIDE))
 			break;
-		if (hipMemcpyAsync(d_origins, origins, sizeof(float) * 3 * ray_count, hipMemcpyHostToDevice, s->stream) != hipSuccess
-			|| hipMemcpyAsync(d_directions, directions, sizeof(float) * 3 * ray_count, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+		uint32_t control[1 + 8 * PT_FETCH_STRIDE];
+		memset(control, 0, sizeof(control));
+		control[0] = ray_count;
+		if (hipMemcpyAsync(d_origins, staging.data(), sizeof(f32x4) * ray_count, hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(d_directions, staging.data() + ray_count, sizeof(f32x4) * ray_count, hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(d_control, control, sizeof(control), hipMemcpyHostToDevice, s->stream) != hipSuccess)
 			break;
-		PtTraceArgs a = pt_trace_args(s, 0, 0);
-		a.stack_overflow = overflow;
-		a.stack_overflow_stride = stride;
-		a.stack_capacity = stack_capacity;
-		hipLaunchKernelGGL(k_trace_user_rays, dim3(pt_grid(ray_count)), dim3(PT_BLOCK), 0, s->stream, a, d_origins, d_directions, ray_count, d_triangles, d_tuv, d_front);
+		PtUserRayArgs a;
+		a.scene = pt_scene_view(s);
+		a.origins = d_origins;
+		a.directions = d_directions;
+		a.count = d_control;
+		a.fetch = d_control + 1;
+		a.stack_overflow = s->stack_overflow;
+		a.stack_overflow_stride = s->stack_overflow_stride;
+		a.stack_capacity = s->stack_capacity;
+		a.cache_layout = pt_cache_layout(s->bvh_info.node_count, s->bvh_info.triangle_count);
+		a.triangles = d_triangles;
+		a.t_u_v = d_tuv;
+		a.front = d_front;
+		hipLaunchKernelGGL(k_trace_user_rays, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 		if (hipMemcpyAsync(triangle_indices, d_triangles, sizeof(int32_t) * ray_count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
 			|| hipMemcpyAsync(t_u_v, d_tuv, sizeof(float) * 3 * ray_count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
 			|| hipMemcpyAsync(front, d_front, ray_count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
@@ -1178,7 +1171,7 @@ extern "C" int pt_trace_rays(pt_scene_t* s, const float* origins, const float* d
 			break;
 		result = 0;
 	} while (0);
-	hipFree(d_origins); hipFree(d_directions); hipFree(d_triangles); hipFree(d_tuv); hipFree(d_front); hipFree(overflow);
+	hipFree(d_origins); hipFree(d_directions); hipFree(d_triangles); hipFree(d_tuv); hipFree(d_front); hipFree(d_control);
 	if (result)
 		printf("Failed to trace %u rays on the GPU.\n", ray_count);
 	return result;

@@ -1,0 +1,336 @@
+// Persistent closest-hit traversal for gfx950 (device code only).
+//
+// One ray per lane walks the 8-wide BVH exactly like pt_trace_closest() in
+// pt_trace.h (same box test, same triangle arithmetic, same tie break, hence
+// bit-identical hits), organised for 64-lane waves:
+//   * Waves are persistent. A lane whose ray is complete does not wait for
+//     the slowest ray of its wave: when enough lanes are idle the wave
+//     refills them from the ray queue in HBM. A wave reserves rays in bulk
+//     with one atomic and then hands them out lane by lane from registers.
+//     Each XCD works through its own contiguous eighth of the queue first, so
+//     its L2 sees rays that started as neighbouring pixels, and steals from
+//     the other eighths afterwards.
+//   * Every pass of the loop does at most one node step and one triangle
+//     test per lane. A leaf with many triangles therefore costs its lane
+//     more passes instead of stalling the other 63 lanes in an inner loop.
+//   * The traversal stack holds one entry per BVH level (a group of sibling
+//     nodes): PT_WAVE_STACK entries per lane in LDS, laid out entry-major so
+//     that a wave's accesses are conflict-free 8-byte words, the rest in HBM.
+//   * One 1024-thread workgroup owns a whole CU and its 160 KB of LDS. What
+//     the stacks leave free (112 KB) holds a prefix of the BVH: the builder
+//     emits nodes, and the triangles of their leaves, in breadth-first order,
+//     so the prefix is the top of the tree - or all of it for a small scene.
+//     Incoherent rays make every lane of a load instruction touch its own
+//     cache line, which the vector L1 serves at a fraction of its bandwidth;
+//     the same gather from LDS is several times faster and ten times closer.
+#pragma once
+#include "pt_common.h"
+#include "pt_trace.h"
+
+#define PT_TRACE_BLOCK 1024   // threads per workgroup of the traversal kernels
+#define PT_WAVES_PER_BLOCK 16
+#define PT_WAVE_STACK 6      // stack entries per lane kept in LDS
+#define PT_CACHE_WORDS 7168  // 16-byte words of BVH prefix kept in LDS (112 KB)
+#ifndef PT_REFILL_MIN
+#define PT_REFILL_MIN 16     // idle lanes that trigger a refill
+#endif
+#ifndef PT_RESERVE
+#define PT_RESERVE 256       // rays a wave reserves from the queue per atomic
+#endif
+#ifndef PT_FETCH_STRIDE
+#define PT_FETCH_STRIDE 32   // words between the fetch counters of the eighths (one 128-byte line each)
+#endif
+#ifndef PT_TRIS_PER_PASS
+#define PT_TRIS_PER_PASS 1   // triangle tests per lane and pass
+#endif
+
+struct PtWaveLds {
+	u32x2 stack[PT_WAVE_STACK][64];
+};
+
+// All LDS of one CU: 112 KB + 16 * 3 KB = 160 KB
+struct PtTraceLds {
+	u32x4 cache[PT_CACHE_WORDS];
+	PtWaveLds wave[PT_WAVES_PER_BLOCK];
+};
+
+// How much of the BVH the LDS prefix holds: nodes first, triangles after them
+struct PtCacheLayout {
+	uint32_t node_count; // nodes [0, node_count) live at cache[5 * index]
+	uint32_t tri_count;  // triangles [0, tri_count) live at cache[tri_offset + 3 * index]
+	uint32_t tri_offset;
+};
+
+__host__ __device__ inline PtCacheLayout pt_cache_layout(uint32_t bvh_node_count, uint32_t bvh_triangle_count) {
+	PtCacheLayout l;
+	l.node_count = (bvh_node_count < PT_CACHE_WORDS / 5) ? bvh_node_count : PT_CACHE_WORDS / 5;
+	l.tri_offset = 5 * l.node_count;
+	uint32_t room = (PT_CACHE_WORDS - l.tri_offset) / 3;
+	l.tri_count = (bvh_triangle_count < room) ? bvh_triangle_count : room;
+	return l;
+}
+
+// Copies the BVH prefix into LDS; the whole workgroup takes part and is
+// synchronised once, after which its waves run independently
+__device__ __forceinline__ void pt_fill_cache(PtTraceLds& lds, const PtCacheLayout& layout, const PtNode* nodes, const PtTri* tris) {
+	const u32x4* node_words = (const u32x4*) nodes;
+	const u32x4* tri_words = (const u32x4*) tris;
+	for (uint32_t i = threadIdx.x; i < 5 * layout.node_count; i += PT_TRACE_BLOCK)
+		lds.cache[i] = node_words[i];
+	for (uint32_t i = threadIdx.x; i < 3 * layout.tri_count; i += PT_TRACE_BLOCK)
+		lds.cache[layout.tri_offset + i] = tri_words[i];
+	__syncthreads();
+}
+
+// Where the rays of one launch come from
+struct PtRayQueue {
+	const f32x4* origin;    // xyz + a word that is handed to finish() (0xffffffff: skip this slot)
+	const f32x4* direction; // xyz + a word that is handed to finish()
+	const uint32_t* count;  // number of rays, in device memory
+	uint32_t* fetch;        // 8 fetch counters (one per eighth, PT_FETCH_STRIDE words apart), zeroed before the launch
+};
+
+// Pointers with an explicit address space: a load through them is a ds_read
+// or a global_load by construction. With generic pointers the compiler merges
+// the LDS and the HBM branch of a fetch into one flat_load, which sends LDS
+// accesses through the vector memory path.
+typedef uint32_t pt_vec4 __attribute__((ext_vector_type(4)));
+typedef uint32_t pt_vec2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) pt_vec4 pt_lds_vec4;
+typedef __attribute__((address_space(1))) pt_vec4 pt_global_vec4;
+typedef __attribute__((address_space(3))) pt_vec2 pt_lds_vec2;
+typedef __attribute__((address_space(1))) pt_vec2 pt_global_vec2;
+
+__device__ __forceinline__ u32x4 pt_to_u32x4(pt_vec4 v) { u32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+__device__ __forceinline__ u32x4 pt_load_lds(const u32x4* p) { return pt_to_u32x4(*(const pt_lds_vec4*) p); }
+__device__ __forceinline__ u32x4 pt_load_global(const u32x4* p) { return pt_to_u32x4(*(const pt_global_vec4*) p); }
+
+__device__ __forceinline__ uint32_t pt_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Calls finish(slot, origin_w, direction_w, hit) once per ray of the queue
+template <bool COUNT_VISITS, typename Finish>
+__device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache, const PtCacheLayout layout, const PtNode* __restrict__ nodes, const PtTri* __restrict__ tris, uint32_t triangle_count,
+	const PtRayQueue& queue, u32x2* stack_overflow, uint32_t stack_overflow_stride, uint32_t stack_capacity,
+	unsigned long long* visit_counters, Finish finish)
+{
+	const uint32_t lane = pt_lane();
+	const uint32_t ray_total = *queue.count;
+	// Eighths of the queue, in multiples of the reservation size
+	const uint32_t chunk_len = ((ray_total + 8 * PT_RESERVE - 1) / (8 * PT_RESERVE)) * PT_RESERVE;
+	uint32_t chunk = blockIdx.x & 7, chunks_tried = 0;
+	// Rays reserved by this wave and not yet handed to a lane (wave-uniform)
+	uint32_t reserve_next = 0, reserve_end = 0;
+	bool rays_remain = ray_total != 0;
+	const float tmin = 1.0e-3f;
+	// Per-lane ray state
+	bool active = false;
+	uint32_t slot = 0;
+	float origin_w = 0.0f, direction_w = 0.0f;
+	v3 origin = mk3(0.0f, 0.0f, 0.0f);
+	float idx = 0.0f, idy = 0.0f, idz = 0.0f;
+	bool neg_x = false, neg_y = false, neg_z = false;
+	uint32_t octinv = 7;
+	PtRayShear shear;
+	shear.kx = 0; shear.ky = 1; shear.kz = 2;
+	shear.sx = shear.sy = shear.sz = 0.0f;
+	PtHit hit;
+	hit.prim = 0xffffffffu;
+	hit.t = 1e38f;
+	hit.u = hit.v = 0.0f;
+	hit.front = false;
+	u32x2 ngroup, tgroup;
+	ngroup.x = ngroup.y = tgroup.x = tgroup.y = 0;
+	uint32_t sp = 0;
+	uint32_t node_visits = 0, tri_visits = 0;
+	uint32_t pass_count = 0, refill_count = 0;
+	unsigned long long active_lane_passes = 0;
+
+	// Every pass retires, fetches, walks or tests something, so the loop ends
+	// when the queue is used up; the bound only guards the GPU against a logic
+	// error ever hanging it.
+	for (uint32_t pass = 0; pass != (1u << 26); ++pass) {
+		// ---- refill idle lanes ----
+		unsigned long long idle_mask = __ballot(!active);
+		if (COUNT_VISITS) {
+			++pass_count;
+			active_lane_passes += 64u - (uint32_t) __popcll(idle_mask);
+		}
+		if (rays_remain && ((uint32_t) __popcll(idle_mask) >= PT_REFILL_MIN)) {
+			if (COUNT_VISITS)
+				++refill_count;
+			if (reserve_next == reserve_end) {
+				// Reserve the next block of rays of this wave's current eighth
+				uint32_t chunk_begin = chunk * chunk_len;
+				uint32_t chunk_end = chunk_begin + chunk_len;
+				if (chunk_end > ray_total) chunk_end = ray_total;
+				uint32_t base = chunk_len;
+				if (chunk_begin < chunk_end) {
+					if (lane == 0)
+						base = atomicAdd(&queue.fetch[chunk * PT_FETCH_STRIDE], (uint32_t) PT_RESERVE);
+					base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+				}
+				if (chunk_begin + base < chunk_end) {
+					reserve_next = chunk_begin + base;
+					reserve_end = reserve_next + PT_RESERVE;
+					if (reserve_end > chunk_end) reserve_end = chunk_end;
+				}
+				else {
+					chunk = (chunk + 1) & 7;
+					if (++chunks_tried == 8)
+						rays_remain = false;
+				}
+			}
+			uint32_t available = reserve_end - reserve_next;
+			if (available) {
+				uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (idle_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) idle_mask, 0u));
+				uint32_t want = (uint32_t) __popcll(idle_mask);
+				if (!active && rank < available) {
+					slot = reserve_next + rank;
+					f32x4 o = queue.origin[slot], d = queue.direction[slot];
+					origin_w = o.w;
+					direction_w = d.w;
+					active = true;
+					sp = 0;
+					tgroup.x = tgroup.y = 0;
+					hit.prim = 0xffffffffu;
+					hit.t = 1e38f;
+					hit.u = hit.v = 0.0f;
+					hit.front = false;
+					if (pt_as_uint(o.w) == 0xffffffffu || triangle_count == 0) {
+						// Padding path or empty scene: a miss without traversal
+						ngroup.x = ngroup.y = 0;
+					}
+					else {
+						origin = mk3(o.x, o.y, o.z);
+						shear = pt_ray_shear(mk3(d.x, d.y, d.z));
+						// The box test may be conservative, so tiny direction
+						// components are clamped to keep reciprocals finite
+						float cdx = (fabsf(d.x) > 1.0e-30f) ? d.x : copysignf(1.0e-30f, d.x);
+						float cdy = (fabsf(d.y) > 1.0e-30f) ? d.y : copysignf(1.0e-30f, d.y);
+						float cdz = (fabsf(d.z) > 1.0e-30f) ? d.z : copysignf(1.0e-30f, d.z);
+						idx = 1.0f / cdx; idy = 1.0f / cdy; idz = 1.0f / cdz;
+						neg_x = cdx < 0.0f; neg_y = cdy < 0.0f; neg_z = cdz < 0.0f;
+						octinv = 7u - ((neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u));
+						ngroup.x = 0;
+						ngroup.y = 0x80000000u;
+					}
+				}
+				reserve_next += (want < available) ? want : available;
+			}
+		}
+		// ---- exit: nothing in flight and nothing left to fetch ----
+		if (!rays_remain && __ballot(active) == 0)
+			break;
+
+		// ---- one node per lane that has no triangles pending ----
+		if (active && tgroup.y == 0) {
+			if (!(ngroup.y & 0xff000000u) && sp != 0) {
+				--sp;
+				pt_vec2 entry;
+				if (sp < PT_WAVE_STACK)
+					entry = *(const pt_lds_vec2*) &lds.stack[sp][lane];
+				else
+					entry = *(const pt_global_vec2*) &stack_overflow[(uint64_t) (sp - PT_WAVE_STACK) * stack_overflow_stride];
+				ngroup.x = entry.x;
+				ngroup.y = entry.y;
+			}
+			if (ngroup.y & 0xff000000u) {
+				uint32_t bit = 31u - (uint32_t) __builtin_clz(ngroup.y);
+				ngroup.y &= ~(1u << bit);
+				if (ngroup.y & 0xff000000u) {
+					pt_vec2 entry;
+					entry.x = ngroup.x;
+					entry.y = ngroup.y;
+					if (sp < PT_WAVE_STACK)
+						*(pt_lds_vec2*) &lds.stack[sp][lane] = entry;
+					else if (sp < stack_capacity)
+						*(pt_global_vec2*) &stack_overflow[(uint64_t) (sp - PT_WAVE_STACK) * stack_overflow_stride] = entry;
+					if (sp < stack_capacity)
+						++sp;
+				}
+				uint32_t child_slot = (bit - 24u) ^ octinv;
+				uint32_t rel = (uint32_t) __builtin_popcount(ngroup.y & 0xffu & ((1u << child_slot) - 1u));
+				uint32_t node_index = ngroup.x + rel;
+				if (COUNT_VISITS)
+					++node_visits;
+				u32x4 w0, w1, w2, w3, w4;
+				if (node_index < layout.node_count) {
+					const u32x4* words = &cache[5 * node_index];
+					w0 = pt_load_lds(words); w1 = pt_load_lds(words + 1); w2 = pt_load_lds(words + 2); w3 = pt_load_lds(words + 3); w4 = pt_load_lds(words + 4);
+				}
+				else {
+					const u32x4* words = (const u32x4*) &nodes[node_index];
+					w0 = pt_load_global(words); w1 = pt_load_global(words + 1); w2 = pt_load_global(words + 2); w3 = pt_load_global(words + 3); w4 = pt_load_global(words + 4);
+				}
+				float sx = pt_as_float((w0.w & 0xffu) << 23), sy = pt_as_float(((w0.w >> 8) & 0xffu) << 23), sz = pt_as_float(((w0.w >> 16) & 0xffu) << 23);
+				uint32_t imask = w0.w >> 24;
+				float ax = idx * sx, ay = idy * sy, az = idz * sz;
+				float bx = (pt_as_float(w0.x) - origin.x) * idx, by = (pt_as_float(w0.y) - origin.y) * idy, bz = (pt_as_float(w0.z) - origin.z) * idz;
+				// Near and far planes per axis, chosen once per node by the ray's signs
+				uint32_t nqx[2] = { neg_x ? w3.z : w2.x, neg_x ? w3.w : w2.y }, fqx[2] = { neg_x ? w2.x : w3.z, neg_x ? w2.y : w3.w };
+				uint32_t nqy[2] = { neg_y ? w4.x : w2.z, neg_y ? w4.y : w2.w }, fqy[2] = { neg_y ? w2.z : w4.x, neg_y ? w2.w : w4.y };
+				uint32_t nqz[2] = { neg_z ? w4.z : w3.x, neg_z ? w4.w : w3.y }, fqz[2] = { neg_z ? w3.x : w4.z, neg_z ? w3.y : w4.w };
+				uint32_t meta[2] = { w1.z, w1.w };
+				uint32_t hitmask = 0;
+#pragma unroll
+				for (int i = 0; i != 8; ++i) {
+					uint32_t m = (meta[i >> 2] >> (8 * (i & 3))) & 0xffu;
+					float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bx), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bx);
+					float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, by), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, by);
+					float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bz), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bz);
+					float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+					float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
+					if (m != 0 && tn <= tf) {
+						if (imask & (1u << i))
+							hitmask |= 1u << (24u + ((uint32_t) i ^ octinv));
+						else
+							hitmask |= (m >> 5) << (m & 31u);
+					}
+				}
+				ngroup.x = w1.x;
+				ngroup.y = (hitmask & 0xff000000u) | imask;
+				tgroup.x = w1.y;
+				tgroup.y = hitmask & 0x00ffffffu;
+			}
+		}
+
+		// ---- one triangle per lane that has triangles pending ----
+		for (int round = 0; round != PT_TRIS_PER_PASS; ++round)
+		if (active && tgroup.y != 0) {
+			uint32_t bit = (uint32_t) __builtin_ctz(tgroup.y);
+			tgroup.y &= tgroup.y - 1u;
+			uint32_t tri_index = tgroup.x + bit;
+			if (COUNT_VISITS)
+				++tri_visits;
+			u32x4 t0, t1, t2;
+			if (tri_index < layout.tri_count) {
+				const u32x4* words = &cache[layout.tri_offset + 3 * tri_index];
+				t0 = pt_load_lds(words); t1 = pt_load_lds(words + 1); t2 = pt_load_lds(words + 2);
+			}
+			else {
+				const u32x4* words = (const u32x4*) &tris[tri_index];
+				t0 = pt_load_global(words); t1 = pt_load_global(words + 1); t2 = pt_load_global(words + 2);
+			}
+			pt_intersect_triangle(hit, shear, origin,
+				mk3(pt_as_float(t0.x), pt_as_float(t0.y), pt_as_float(t0.z)),
+				mk3(pt_as_float(t0.w), pt_as_float(t1.x), pt_as_float(t1.y)),
+				mk3(pt_as_float(t1.z), pt_as_float(t1.w), pt_as_float(t2.x)), t2.y, tmin);
+		}
+
+		// ---- retire complete rays ----
+		if (active && !(ngroup.y & 0xff000000u) && sp == 0 && tgroup.y == 0) {
+			finish(slot, origin_w, direction_w, hit);
+			active = false;
+		}
+	}
+	if (COUNT_VISITS) {
+		atomicAdd(&visit_counters[0], (unsigned long long) node_visits);
+		atomicAdd(&visit_counters[1], (unsigned long long) tri_visits);
+		if (lane == 0) {
+			// Diagnostics: passes, lanes active in them, refills (summed over waves)
+			atomicAdd(&visit_counters[6], (unsigned long long) pass_count);
+			atomicAdd(&visit_counters[7], active_lane_passes);
+			atomicAdd(&visit_counters[10], (unsigned long long) refill_count);
+		}
+	}
+}

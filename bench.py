@@ -18,6 +18,33 @@ sys.path.insert(0, ROOT)
 DATA_ROOT = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0
 
+# workload -> (scene name, texture directory, quicksave below data/saves, label, default triangle budget)
+WORKLOADS = {
+    "cornell": ("cornell_box", "cornell_box_textures", "cornell_box/default.rt_save", "Cornell box", None),
+    "city": ("Bistro_outside", "Bistro_textures", "bistro/outside.rt_save", "Generated city block (Bistro exterior stand-in, the reference's Bistro lights and camera)", 2800000),
+    "interior": ("Arcade", "Arcade_textures", "Arcade/default.rt_save", "Generated hall with 32 lights (Arcade stand-in)", 1000000),
+}
+
+
+def workload_root(args, rank, barrier=None):
+    """The directory that holds data/ for the workload; generated scenes are built once per box by rank 0."""
+    if args.workload == "cornell":
+        return DATA_ROOT
+    from path_tracer_amd.tools import procedural
+    triangles = args.triangles or WORKLOADS[args.workload][4]
+    root = os.path.join(args.scene_cache, "%s_%d" % (args.workload, triangles))
+    if rank == 0:
+        options = {"triangles": triangles}
+        if args.workload == "city":
+            options["lights_file"] = os.path.join(DATA_ROOT, "data", "Bistro_outside.lights")
+            options["save_file"] = os.path.join(DATA_ROOT, "data", "saves", "bistro", "outside.rt_save")
+        begin = time.perf_counter()
+        procedural.ensure_scene(args.workload, root, **options)
+        print("workload %s ready under %s (%.1f s)" % (args.workload, root, time.perf_counter() - begin), file=sys.stderr)
+    if barrier is not None:
+        barrier()
+    return root
+
 
 def parse_args():
     p = argparse.ArgumentParser()
@@ -29,6 +56,10 @@ def parse_args():
     p.add_argument("--spp-per-step", type=int, default=32)
     p.add_argument("--path-length", type=int, default=4)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--workload", choices=sorted(WORKLOADS), default="cornell",
+                   help="cornell: the reference's own scene file; city / interior: generated stand-ins for Bistro exterior / Arcade")
+    p.add_argument("--triangles", type=int, default=None, help="triangle budget of a generated workload")
+    p.add_argument("--scene-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "pt_scenes"))
     return p.parse_args()
 
 
@@ -41,22 +72,23 @@ def trace_bytes_per_ray(kind, nodes_per_ray, tris_per_ray, node_bytes, tri_bytes
     return stream + nodes_per_ray * node_bytes + tris_per_ray * tri_bytes
 
 
-def cpu_baseline(args, threads):
+def cpu_baseline(args, threads, root, first_frame_index):
     """The CPU oracle on a bounded sample of the same workload (reported baseline, not the target)."""
     import oracle
     from oracle import formats
-    data = os.path.join(DATA_ROOT, "data")
-    scene = formats.load_scene(os.path.join(data, "cornell_box.vks"), os.path.join(data, "cornell_box_textures"))
-    lights = formats.load_lights(os.path.join(data, "cornell_box.lights"))
-    spec = formats.load_rt_save(os.path.join(data, "saves", "cornell_box", "default.rt_save"))
-    width, height, spp = args.width // 2, args.height // 2, 16
+    data = os.path.join(root, "data")
+    name, textures, save, label, _ = WORKLOADS[args.workload]
+    scene = formats.load_scene(os.path.join(data, name + ".vks"), os.path.join(data, textures))
+    lights = formats.load_lights(os.path.join(data, name + ".lights"))
+    spec = formats.load_rt_save(os.path.join(data, "saves", save))
+    width, height, spp = args.width // 2, args.height // 2, (16 if args.workload == "cornell" else 4)
     constants = oracle.write_constants(spec, width, height, scene, lights)
     cpu_scene = oracle.OracleScene(scene)
     begin = time.perf_counter()
-    _, rays = cpu_scene.render(constants, lights, strategy=3, path_length=args.path_length, first_frame_index=2696, frame_count=spp, threads=threads)
+    _, rays = cpu_scene.render(constants, lights, strategy=3, path_length=args.path_length, first_frame_index=first_frame_index, frame_count=spp, threads=threads)
     seconds = time.perf_counter() - begin
     return {"value": rays / seconds * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "sample": "CPU oracle, Cornell box %dx%d, %d spp, NEE, path length %d, %d rays in %.2f s" % (width, height, spp, args.path_length, rays, seconds)}
+            "sample": "CPU oracle, %s %dx%d, %d spp, NEE, path length %d, %d rays in %.2f s" % (label, width, height, spp, args.path_length, rays, seconds)}
 
 
 def main():
@@ -77,8 +109,10 @@ def main():
     if world_size > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
 
-    spec = host_api.quickload(os.path.join(DATA_ROOT, "data", "saves", "cornell_box", "default.rt_save"))
-    renderer = host_api.Renderer(spec, DATA_ROOT, device=local_rank, width=args.width, height=args.height,
+    root = workload_root(args, rank, dist.barrier if world_size > 1 else None)
+    name, _, save, label, _ = WORKLOADS[args.workload]
+    spec = host_api.quickload(os.path.join(root, "data", "saves", save))
+    renderer = host_api.Renderer(spec, root, device=local_rank, width=args.width, height=args.height,
                                  sampling_strategy=hip_api.SAMPLING_STRATEGY_NEE, path_length=args.path_length)
     constants = renderer.constants()
     lib = hip_api.lib()
@@ -155,8 +189,9 @@ def main():
             "metric": "Mrays/s", "value": total_rays / seconds * 1e-6, "unit": "Mrays/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": seconds / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "Cornell box scene file of the reference (fixture copy of data/cornell_box.vks, its textures, lights and quicksave)",
-            "config": {"workload": "Cornell box %dx%d, NEE + MIS, path length %d, %d spp per step per GPU, frames %d.." % (args.width, args.height, args.path_length, spp, spec.frame_index + 1),
+            "data": ("Cornell box scene file of the reference (fixture copy of data/cornell_box.vks, its textures, lights and quicksave)" if args.workload == "cornell"
+                     else "synthetic: scene generated by path_tracer_amd/tools/procedural.py in the reference's file formats"),
+            "config": {"workload": "%s %dx%d, NEE + MIS, path length %d, %d spp per step per GPU, frames %d.." % (label, args.width, args.height, args.path_length, spp, spec.frame_index + 1),
                        "spp_total": args.steps * spp * world_size, "parallelism": "sample slices x%d + all-reduce" % world_size},
             "samples_per_s": total_paths / seconds,
             "rays_per_path": total_rays / total_paths,
@@ -168,7 +203,7 @@ def main():
             "bvh": {"nodes": info.node_count, "triangles": info.triangle_count, "depth": info.depth, "build_ms": info.build_ms},
         }
         if not args.no_cpu_baseline and world_size == 1:
-            result["cpu_baseline"] = cpu_baseline(args, min(16, os.cpu_count() or 1))
+            result["cpu_baseline"] = cpu_baseline(args, min(16, os.cpu_count() or 1), root, spec.frame_index + 1)
         else:
             result["cpu_baseline"] = None
         C.CDLL(None).fflush(None)

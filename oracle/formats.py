@@ -150,3 +150,23 @@ def default_scene_spec() -> np.ndarray:
     spec["emission_material_color"] = (1.0, 0.9, 0.6)
     spec["emission_material_strength"] = 20.0
     return spec
+
+
+def dequantize_positions(scene: Scene) -> np.ndarray:
+    """World-space vertex positions (3 * triangle_count, 3), float32, with the arithmetic of src/scene.c:43-55:
+    21 bits per coordinate out of two words, multiplied by the factor, then the summand added."""
+    words = scene.positions.astype(np.uint32)
+    quantized = np.stack([words[:, 0] & 0x1fffff, ((words[:, 0] & 0xffe00000) >> 21) | ((words[:, 1] & 0x3ff) << 11),
+                          (words[:, 1] & 0x7ffffc00) >> 10], axis=1).astype(np.float32)
+    return quantized * scene.dequantization_factor.astype(np.float32) + scene.dequantization_summand.astype(np.float32)
+
+
+def decode_normals(scene: Scene) -> np.ndarray:
+    """Unit vertex normals (3 * triangle_count, 3) from the octahedral map, as dequantize_normal() at
+    src/shaders/mesh_quantization.glsl:16-34 decodes them: 32768 is zero, 1 is -1 (float64 here: for checks with a
+    tolerance, not bit-exact)."""
+    octahedral = (scene.normals_uvs[:, 0:2].astype(np.float64) - 32768.0) / 32767.0
+    normal = np.concatenate([octahedral, (1.0 - np.abs(octahedral[:, 0]) - np.abs(octahedral[:, 1]))[:, None]], axis=1)
+    folded = (1.0 - np.abs(normal[:, 1::-1])) * np.where(normal[:, 0:2] >= 0.0, 1.0, -1.0)
+    normal[:, 0:2] = np.where(normal[:, 2:3] < 0.0, folded, normal[:, 0:2])
+    return normal / np.linalg.norm(normal, axis=1, keepdims=True)

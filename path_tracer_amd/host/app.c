@@ -251,7 +251,7 @@ int save_screenshot(const char* file_path, image_file_format_t format, lit_scene
 			printf("Failed to save a HDR screenshot to %s. Please check path, permissions and available disk space.\n", file_path);
 		free(hdr_copy);
 	}
-	else if (format == image_file_format_png) {
+	else if (format == image_file_format_png || format == image_file_format_jpg) {
 		uint8_t* ldr_copy = malloc(pixel_count * 3);
 		float factor = scene_spec->exposure / ((float) accum_frame_count);
 		for (size_t p = 0; p != pixel_count; ++p) {
@@ -263,13 +263,13 @@ int save_screenshot(const char* file_path, image_file_format_t format, lit_scene
 				ldr_copy[3 * p + i] = (uint8_t) (srgb * 255.0f + 0.5f);
 			}
 		}
-		result = write_png(file_path, width, height, ldr_copy);
+		result = (format == image_file_format_jpg) ? write_jpg(file_path, width, height, ldr_copy, 90) : write_png(file_path, width, height, ldr_copy);
 		if (result)
 			printf("Failed to save a screenshot to %s. Please check path, permissions and available disk space.\n", file_path);
 		free(ldr_copy);
 	}
 	else {
-		printf("Failed to save a screenshot to %s. JPG output is not supported; use PNG or HDR.\n", file_path);
+		printf("Failed to save a screenshot to %s. The image file format %d is unknown.\n", file_path, (int) format);
 		result = 1;
 	}
 	free(floats);

@@ -121,3 +121,201 @@ int write_png(const char* file_path, uint32_t width, uint32_t height, const uint
 	free(z);
 	return fclose(file) != 0;
 }
+
+
+/* ---- Baseline JPEG (JFIF, 8-bit, YCbCr 4:4:4, the example Huffman and
+ * quantisation tables of ITU-T T.81 annex K). Replaces stbi_write_jpg of the
+ * vendored stb_image_write.h, which save_screenshot() calls with quality 90
+ * (src/main.c:2068). ---- */
+
+static const uint8_t jpg_zigzag[64] = {
+	0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+	35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63 };
+static const uint8_t jpg_quant_luma[64] = {
+	16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+	18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99 };
+static const uint8_t jpg_quant_chroma[64] = {
+	17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+	99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99 };
+static const uint8_t jpg_dc_luma_bits[16] = { 0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0 };
+static const uint8_t jpg_dc_chroma_bits[16] = { 0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0 };
+static const uint8_t jpg_dc_values[12] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11 };
+static const uint8_t jpg_ac_luma_bits[16] = { 0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d };
+static const uint8_t jpg_ac_luma_values[162] = {
+	0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08,
+	0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28,
+	0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59,
+	0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89,
+	0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6,
+	0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2,
+	0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa };
+static const uint8_t jpg_ac_chroma_bits[16] = { 0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77 };
+static const uint8_t jpg_ac_chroma_values[162] = {
+	0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91,
+	0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26,
+	0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58,
+	0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87,
+	0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4,
+	0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda,
+	0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa };
+
+typedef struct { uint16_t code[256]; uint8_t length[256]; } jpg_huffman_t;
+typedef struct { FILE* file; uint32_t bits; int bit_count; } jpg_writer_t;
+
+static void jpg_build_huffman(jpg_huffman_t* table, const uint8_t* bits, const uint8_t* values) {
+	memset(table, 0, sizeof(*table));
+	uint32_t code = 0, k = 0;
+	for (uint32_t length = 1; length <= 16; ++length) {
+		for (uint32_t i = 0; i != bits[length - 1]; ++i, ++k) {
+			table->code[values[k]] = (uint16_t) code++;
+			table->length[values[k]] = (uint8_t) length;
+		}
+		code <<= 1;
+	}
+}
+
+static void jpg_put_bits(jpg_writer_t* w, uint32_t code, int length) {
+	w->bits = (w->bits << length) | (code & ((1u << length) - 1u));
+	w->bit_count += length;
+	while (w->bit_count >= 8) {
+		uint8_t byte = (uint8_t) (w->bits >> (w->bit_count - 8));
+		fputc(byte, w->file);
+		if (byte == 0xff)
+			fputc(0, w->file);
+		w->bit_count -= 8;
+	}
+}
+
+static void jpg_put_segment(FILE* file, uint8_t marker, const uint8_t* payload, uint32_t size) {
+	uint8_t head[4] = { 0xff, marker, (uint8_t) ((size + 2) >> 8), (uint8_t) (size + 2) };
+	fwrite(head, 1, 4, file);
+	fwrite(payload, 1, size, file);
+}
+
+static void jpg_encode_block(jpg_writer_t* w, const float* samples, const uint8_t* quant, int* previous_dc, const jpg_huffman_t* dc, const jpg_huffman_t* ac) {
+	static float cosines[8][8];
+	static int cosines_ready = 0;
+	if (!cosines_ready) {
+		for (int u = 0; u != 8; ++u)
+			for (int x = 0; x != 8; ++x)
+				cosines[u][x] = (float) (((u == 0) ? sqrt(0.125) : 0.5) * cos((2 * x + 1) * u * M_PI / 16.0));
+		cosines_ready = 1;
+	}
+	float rows[64], coefficients[64];
+	for (int y = 0; y != 8; ++y)
+		for (int u = 0; u != 8; ++u) {
+			float sum = 0.0f;
+			for (int x = 0; x != 8; ++x)
+				sum += cosines[u][x] * samples[8 * y + x];
+			rows[8 * y + u] = sum;
+		}
+	for (int v = 0; v != 8; ++v)
+		for (int u = 0; u != 8; ++u) {
+			float sum = 0.0f;
+			for (int y = 0; y != 8; ++y)
+				sum += cosines[v][y] * rows[8 * y + u];
+			coefficients[8 * v + u] = sum;
+		}
+	int quantized[64];
+	for (int i = 0; i != 64; ++i)
+		quantized[i] = (int) lrintf(coefficients[jpg_zigzag[i]] / (float) quant[jpg_zigzag[i]]);
+	// DC difference, then run-length coded AC coefficients
+	int values[2] = { quantized[0] - *previous_dc, 0 };
+	*previous_dc = quantized[0];
+	int run = 0;
+	for (int i = 0; i != 64; ++i) {
+		int value = (i == 0) ? values[0] : quantized[i];
+		if (i != 0 && value == 0) {
+			++run;
+			continue;
+		}
+		int magnitude = abs(value), size = 0;
+		while (magnitude >> size)
+			++size;
+		uint32_t extra = (uint32_t) ((value < 0) ? value - 1 : value);
+		if (i == 0)
+			jpg_put_bits(w, dc->code[size], dc->length[size]);
+		else {
+			for (; run >= 16; run -= 16)
+				jpg_put_bits(w, ac->code[0xf0], ac->length[0xf0]);
+			jpg_put_bits(w, ac->code[(run << 4) | size], ac->length[(run << 4) | size]);
+			run = 0;
+		}
+		if (size)
+			jpg_put_bits(w, extra, size);
+	}
+	if (run)
+		jpg_put_bits(w, ac->code[0], ac->length[0]);
+}
+
+int write_jpg(const char* file_path, uint32_t width, uint32_t height, const uint8_t* rgb, int quality) {
+	if (width == 0 || height == 0 || width > 65535 || height > 65535)
+		return 1;
+	FILE* file = fopen(file_path, "wb");
+	if (!file)
+		return 1;
+	quality = (quality < 1) ? 1 : ((quality > 100) ? 100 : quality);
+	int scale = (quality < 50) ? 5000 / quality : 200 - 2 * quality;
+	uint8_t tables[2][64], segment[2][65];
+	for (int t = 0; t != 2; ++t) {
+		segment[t][0] = (uint8_t) t;
+		for (int i = 0; i != 64; ++i) {
+			int q = (((t == 0) ? jpg_quant_luma[i] : jpg_quant_chroma[i]) * scale + 50) / 100;
+			tables[t][i] = (uint8_t) ((q < 1) ? 1 : ((q > 255) ? 255 : q));
+		}
+		for (int i = 0; i != 64; ++i)
+			segment[t][1 + i] = tables[t][jpg_zigzag[i]];
+	}
+	static const uint8_t soi[2] = { 0xff, 0xd8 };
+	static const uint8_t jfif[14] = { 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0 };
+	fwrite(soi, 1, 2, file);
+	jpg_put_segment(file, 0xe0, jfif, sizeof(jfif));
+	jpg_put_segment(file, 0xdb, segment[0], 65);
+	jpg_put_segment(file, 0xdb, segment[1], 65);
+	uint8_t frame[15] = { 8, (uint8_t) (height >> 8), (uint8_t) height, (uint8_t) (width >> 8), (uint8_t) width, 3, 1, 0x11, 0, 2, 0x11, 1, 3, 0x11, 1 };
+	jpg_put_segment(file, 0xc0, frame, sizeof(frame));
+	const uint8_t* bit_lists[4] = { jpg_dc_luma_bits, jpg_ac_luma_bits, jpg_dc_chroma_bits, jpg_ac_chroma_bits };
+	const uint8_t* value_lists[4] = { jpg_dc_values, jpg_ac_luma_values, jpg_dc_values, jpg_ac_chroma_values };
+	static const uint8_t classes[4] = { 0x00, 0x10, 0x01, 0x11 };
+	jpg_huffman_t huffman[4];
+	for (int t = 0; t != 4; ++t) {
+		uint8_t payload[1 + 16 + 162];
+		uint32_t count = 0;
+		for (int i = 0; i != 16; ++i)
+			count += bit_lists[t][i];
+		payload[0] = classes[t];
+		memcpy(payload + 1, bit_lists[t], 16);
+		memcpy(payload + 17, value_lists[t], count);
+		jpg_put_segment(file, 0xc4, payload, 17 + count);
+		jpg_build_huffman(&huffman[t], bit_lists[t], value_lists[t]);
+	}
+	static const uint8_t scan[10] = { 3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0 };
+	jpg_put_segment(file, 0xda, scan, sizeof(scan));
+	jpg_writer_t writer = { file, 0, 0 };
+	int previous_dc[3] = { 0, 0, 0 };
+	for (uint32_t by = 0; by < height; by += 8) {
+		for (uint32_t bx = 0; bx < width; bx += 8) {
+			float planes[3][64];
+			for (uint32_t y = 0; y != 8; ++y) {
+				for (uint32_t x = 0; x != 8; ++x) {
+					// Blocks that reach over the border repeat the last row and column
+					uint32_t sx = (bx + x < width) ? bx + x : width - 1, sy = (by + y < height) ? by + y : height - 1;
+					const uint8_t* p = &rgb[3 * ((size_t) sy * width + sx)];
+					float r = p[0], g = p[1], b = p[2];
+					planes[0][8 * y + x] = 0.299f * r + 0.587f * g + 0.114f * b - 128.0f;
+					planes[1][8 * y + x] = -0.168736f * r - 0.331264f * g + 0.5f * b;
+					planes[2][8 * y + x] = 0.5f * r - 0.418688f * g - 0.081312f * b;
+				}
+			}
+			jpg_encode_block(&writer, planes[0], tables[0], &previous_dc[0], &huffman[0], &huffman[1]);
+			jpg_encode_block(&writer, planes[1], tables[1], &previous_dc[1], &huffman[2], &huffman[3]);
+			jpg_encode_block(&writer, planes[2], tables[1], &previous_dc[2], &huffman[2], &huffman[3]);
+		}
+	}
+	if (writer.bit_count)
+		jpg_put_bits(&writer, 0x7f, 8 - writer.bit_count);
+	static const uint8_t eoi[2] = { 0xff, 0xd9 };
+	fwrite(eoi, 1, 2, file);
+	int failed = ferror(file);
+	return (fclose(file) != 0) || failed;
+}

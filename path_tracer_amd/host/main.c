@@ -1,8 +1,7 @@
 /* Headless command line driver: loads a quicksave and its scene, renders a
- * number of samples per pixel on one GPU and writes a screenshot. It covers
- * what one slide of the reference's slideshow does (src/slides.c,
- * show_slide() at src/main.c:1482: quicksave + render settings + sample count
- * -> image) without window or GUI. */
+ * number of samples per pixel on one GPU and writes a screenshot, or runs a
+ * range of the reference's slides (-bN -eN, src/main.c:2111-2112) as a batch
+ * job. No window, no GUI. */
 #include "pt_host.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -11,15 +10,20 @@
 
 static void print_usage(void) {
 	printf("Usage: pt_render [-data ROOT] [-save FILE.rt_save] [-scene N] [-wWIDTH] [-hHEIGHT] [-spp N] [-path_length N]\n"
-		"                 [-strategy spherical|psa|brdf|nee] [-device N] [-o OUT.png|OUT.hdr]\n"
-		"ROOT is the directory holding data/ (default: the working directory, like the reference).\n");
+		"                 [-strategy spherical|psa|brdf|nee] [-device N] [-o OUT.png|OUT.jpg|OUT.hdr] [-display]\n"
+		"       pt_render -bBEGIN -eEND [-data ROOT] [-out ROOT] [-no_screenshots] [-max_spp N] [-wWIDTH] [-hHEIGHT]\n"
+		"ROOT is the directory holding data/ (default: the working directory, like the reference).\n"
+		"-display saves what the window would show (tonemapper and exposure of the quicksave) instead of a screenshot.\n"
+		"-bBEGIN -eEND runs slides BEGIN to END-1; screenshots go to renders/ below -out.\n");
 }
 
 int main(int argc, char** argv) {
 	const char* data_root = "";
 	const char* save_path = NULL;
 	const char* out_path = "screenshot.png";
-	int scene_override = -1, device = 0;
+	const char* output_root = ".";
+	int scene_override = -1, device = 0, display = 0, slide_screenshots = 1;
+	uint32_t slide_begin = 0, slide_end = 0, max_spp = 0;
 	uint32_t width = 1280, height = 1024, spp = 64;
 	render_settings_t settings;
 	init_render_settings(&settings);
@@ -32,6 +36,12 @@ int main(int argc, char** argv) {
 		else if (!strcmp(arg, "-path_length") && i + 1 < argc) settings.path_length = (uint32_t) atoi(argv[++i]);
 		else if (!strcmp(arg, "-device") && i + 1 < argc) device = atoi(argv[++i]);
 		else if (!strcmp(arg, "-o") && i + 1 < argc) out_path = argv[++i];
+		else if (!strcmp(arg, "-out") && i + 1 < argc) output_root = argv[++i];
+		else if (!strcmp(arg, "-display")) display = 1;
+		else if (!strcmp(arg, "-no_screenshots")) slide_screenshots = 0;
+		else if (!strcmp(arg, "-max_spp") && i + 1 < argc) max_spp = (uint32_t) atoi(argv[++i]);
+		else if (arg[0] == '-' && arg[1] == 'b' && arg[2]) slide_begin = (uint32_t) atoi(arg + 2);
+		else if (arg[0] == '-' && arg[1] == 'e' && arg[2]) slide_end = (uint32_t) atoi(arg + 2);
 		else if (!strcmp(arg, "-strategy") && i + 1 < argc) {
 			const char* name = argv[++i];
 			if (!strcmp(name, "spherical")) settings.sampling_strategy = sampling_strategy_spherical;
@@ -46,6 +56,16 @@ int main(int argc, char** argv) {
 			print_usage();
 			return 1;
 		}
+	}
+	if (slide_begin < slide_end) {
+		slideshow_t* show = calloc(1, sizeof(slideshow_t));
+		create_slides(show);
+		show->slide_begin = slide_begin;
+		show->slide_end = slide_end;
+		int failed = run_slideshow(show, device, data_root, output_root, width, height, slide_screenshots, max_spp);
+		free_slideshow(show);
+		free(show);
+		return failed;
 	}
 	scene_spec_t spec;
 	init_scene_spec(&spec);
@@ -82,8 +102,10 @@ int main(int argc, char** argv) {
 			printf("Rendered %u spp at %ux%u in %.3f s: %.1f Mrays/s, %.1f Msamples/s.\n", spp, width, height, seconds,
 				(double) (stats.extension_rays + stats.shadow_rays) / seconds * 1.0e-6, (double) width * height * spp / seconds * 1.0e-6);
 		size_t length = strlen(out_path);
-		image_file_format_t format = (length > 4 && !strcmp(out_path + length - 4, ".hdr")) ? image_file_format_hdr : image_file_format_png;
-		result = save_screenshot(out_path, format, &lit_scene, &targets, &spec);
+		image_file_format_t format = image_file_format_png;
+		if (length > 4 && !strcmp(out_path + length - 4, ".hdr")) format = image_file_format_hdr;
+		if (length > 4 && !strcmp(out_path + length - 4, ".jpg")) format = image_file_format_jpg;
+		result = display ? save_display_image(out_path, format, &lit_scene, &targets, &spec) : save_screenshot(out_path, format, &lit_scene, &targets, &spec);
 		if (!result)
 			printf("Saved %s.\n", out_path);
 	}

@@ -8,6 +8,7 @@
 #ifndef PT_HOST_H
 #define PT_HOST_H
 #include <stdbool.h>
+#include <stddef.h>
 #include <stdint.h>
 #include "../../include/pt_hip.h"
 
@@ -201,14 +202,52 @@ int write_constant_buffer(constants_t* constants, const scene_spec_t* scene_spec
  * frame (src/main.c:1624), then the frame is rendered and accumulated
  * (src/main.c:1842-1891). */
 int render_frames(scene_spec_t* scene_spec, lit_scene_t* lit_scene, render_targets_t* render_targets, uint32_t frame_count);
-/* src/main.c:1986-2086. PNG and HDR are written by this library's own
- * encoders; JPG is not supported. */
+/* src/main.c:1986-2086. PNG, JPG (quality 90) and HDR are written by this
+ * library's own encoders. */
 int save_screenshot(const char* file_path, image_file_format_t format, lit_scene_t* lit_scene, const render_targets_t* render_targets, const scene_spec_t* scene_spec);
 
 /* Image writers (replace stbi_write_hdr / stbi_write_png of the vendored
  * stb_image_write.h) */
 int write_hdr(const char* file_path, uint32_t width, uint32_t height, const float* rgb);
 int write_png(const char* file_path, uint32_t width, uint32_t height, const uint8_t* rgb);
+int write_jpg(const char* file_path, uint32_t width, uint32_t height, const uint8_t* rgb, int quality);
+
+/* The tonemap pass (src/shaders/tonemap.frag.glsl:67-82) and the sRGB encoding
+ * of the swapchain on the host. hdr_radiance is RGBA, the sum over
+ * accum_frame_count frames; out_rgb is linear Rec. 709 before the display
+ * encoding, out_srgb 3 bytes per pixel after it. */
+void tonemap_pixel(float out_rgb[3], const float hdr_radiance[4], float exposure, uint32_t accum_frame_count, tonemapper_t tonemapper);
+void tonemap_image(uint8_t* out_srgb, const float* hdr_radiance, size_t pixel_count, float exposure, uint32_t accum_frame_count, tonemapper_t tonemapper);
+/* Saves what the window of the reference would show for the current
+ * accumulation (tonemapper and exposure of scene_spec) as PNG or JPG. */
+int save_display_image(const char* file_path, image_file_format_t format, lit_scene_t* lit_scene, const render_targets_t* render_targets, const scene_spec_t* scene_spec);
+
+/* Slides (src/main.h:120-150) */
+#define MAX_SLIDE_COUNT 100
+typedef struct {
+	/* Quicksave to load, relative to the data root (e.g. data/saves/bistro/pretty.rt_save) */
+	char* quicksave;
+	render_settings_t render_settings;
+	/* Where the screenshot goes, relative to the output root, or NULL */
+	char* screenshot_path;
+	image_file_format_t screenshot_format;
+	/* The number of accumulated frames at which the screenshot is taken */
+	uint32_t screenshot_frame;
+} slide_t;
+typedef struct {
+	slide_t slides[MAX_SLIDE_COUNT];
+	uint32_t slide_count;
+	uint32_t slide_begin, slide_end;
+	uint32_t slide_current;
+} slideshow_t;
+/* src/slides.c:5-142 */
+uint32_t create_slides(slideshow_t* slideshow);
+void free_slideshow(slideshow_t* slideshow);
+/* Shows slides [slide_begin, slide_end) one after the other: quickload, render
+ * settings, screenshot_frame frames (at most frame_limit if that is nonzero),
+ * screenshot below output_root unless slide_screenshots is 0 (the
+ * -no_screenshots switch of src/main.c:2110). */
+int run_slideshow(slideshow_t* slideshow, int device_index, const char* data_root, const char* output_root, uint32_t width, uint32_t height, int slide_screenshots, uint32_t frame_limit);
 
 #ifdef __cplusplus
 }

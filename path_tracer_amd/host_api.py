@@ -75,6 +75,18 @@ class HostTextures(C.Structure):
 
 
 IMAGE_FILE_FORMAT_PNG, IMAGE_FILE_FORMAT_JPG, IMAGE_FILE_FORMAT_HDR = range(3)
+TONEMAPPER_CLAMP, TONEMAPPER_ACES, TONEMAPPER_KHRONOS_PBR_NEUTRAL = range(3)
+MAX_SLIDE_COUNT = 100
+
+
+class Slide(C.Structure):
+    _fields_ = [("quicksave", C.c_char_p), ("render_settings", RenderSettings), ("screenshot_path", C.c_char_p),
+                ("screenshot_format", C.c_int), ("screenshot_frame", C.c_uint32)]
+
+
+class Slideshow(C.Structure):
+    _fields_ = [("slides", Slide * MAX_SLIDE_COUNT), ("slide_count", C.c_uint32), ("slide_begin", C.c_uint32), ("slide_end", C.c_uint32),
+                ("slide_current", C.c_uint32)]
 
 _lib = None
 
@@ -119,6 +131,17 @@ def lib():
         _lib.save_screenshot.argtypes = [C.c_char_p, i32, C.POINTER(LitScene), C.POINTER(RenderTargets), C.POINTER(SceneSpec)]
         _lib.write_hdr.argtypes = [C.c_char_p, u32, u32, vp]
         _lib.write_png.argtypes = [C.c_char_p, u32, u32, vp]
+        _lib.write_jpg.argtypes = [C.c_char_p, u32, u32, vp, i32]
+        _lib.tonemap_pixel.argtypes = [f32p, f32p, C.c_float, u32, i32]
+        _lib.tonemap_pixel.restype = None
+        _lib.tonemap_image.argtypes = [vp, vp, C.c_size_t, C.c_float, u32, i32]
+        _lib.tonemap_image.restype = None
+        _lib.save_display_image.argtypes = [C.c_char_p, i32, C.POINTER(LitScene), C.POINTER(RenderTargets), C.POINTER(SceneSpec)]
+        _lib.create_slides.argtypes = [C.POINTER(Slideshow)]
+        _lib.create_slides.restype = u32
+        _lib.free_slideshow.argtypes = [C.POINTER(Slideshow)]
+        _lib.free_slideshow.restype = None
+        _lib.run_slideshow.argtypes = [C.POINTER(Slideshow), i32, C.c_char_p, C.c_char_p, u32, u32, i32, u32]
     return _lib
 
 
@@ -190,8 +213,13 @@ class Renderer:
 
     def save_screenshot(self, path, image_format=None):
         if image_format is None:
-            image_format = IMAGE_FILE_FORMAT_HDR if path.endswith(".hdr") else IMAGE_FILE_FORMAT_PNG
+            image_format = IMAGE_FILE_FORMAT_HDR if path.endswith(".hdr") else (IMAGE_FILE_FORMAT_JPG if path.endswith(".jpg") else IMAGE_FILE_FORMAT_PNG)
         _check(lib().save_screenshot(os.fsencode(path), image_format, C.byref(self.lit_scene), C.byref(self.targets), C.byref(self.spec)), "save_screenshot")
+
+    def save_display_image(self, path, image_format=None):
+        if image_format is None:
+            image_format = IMAGE_FILE_FORMAT_JPG if path.endswith(".jpg") else IMAGE_FILE_FORMAT_PNG
+        _check(lib().save_display_image(os.fsencode(path), image_format, C.byref(self.lit_scene), C.byref(self.targets), C.byref(self.spec)), "save_display_image")
 
     def statistics(self):
         stats = hip_api.Statistics()

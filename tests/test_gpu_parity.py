@@ -264,3 +264,47 @@ def test_error_behaviour(gpu_cornell, cornell, cornell_lights, cornell_spec, cap
     C.CDLL(None).fflush(None)
     out = capfd.readouterr().out
     assert "does not match" in out and "not supported" in out
+
+
+def test_slideshow_cornell_path_lengths(tmp_path, cornell, cornell_lights, cornell_spec, oracle_cornell):
+    """Slides 24..33 of the reference (Cornell box, path lengths 0..9) as a batch job; screenshots equal the oracle's."""
+    from PIL import Image
+    show = host_api.Slideshow()
+    host_api.lib().create_slides(C.byref(show))
+    show.slide_begin, show.slide_end = 24, 28
+    frames = 3
+    assert host_api.lib().run_slideshow(C.byref(show), 0, os.fsencode(DATA_ROOT), os.fsencode(str(tmp_path)), 96, 64, 1, frames) == 0
+    constants = oracle.write_constants(cornell_spec, 96, 64, cornell, cornell_lights)
+    for path_length in range(4):
+        expected, _ = oracle_cornell.render(constants, cornell_lights, path_length=path_length, first_frame_index=2696, frame_count=frames, threads=8)
+        ldr = np.clip(expected[..., :3] * np.float32(1.0 / frames), 0, 1)
+        srgb = np.where(ldr <= 0.0031308, 12.92 * ldr, 1.055 * ldr ** (1 / 2.4) - 0.055)
+        got = np.asarray(Image.open(str(tmp_path / "renders" / "cornell_box_path_lengths" / ("%d.png" % path_length))))
+        assert got.shape == (64, 96, 3) and np.abs(got.astype(int) - (srgb * 255 + 0.5).astype(np.uint8)).max() <= 1
+    assert not os.path.exists(str(tmp_path / "renders" / "cornell_box_path_lengths" / "4.png"))
+    host_api.lib().free_slideshow(C.byref(show))
+
+
+def test_display_image_and_jpg(tmp_path):
+    from PIL import Image
+    spec = host_api.quickload(os.path.join(DATA, "saves", "cornell_box", "default.rt_save"))
+    renderer = host_api.Renderer(spec, DATA_ROOT, device=0, width=64, height=48)
+    renderer.render_frames(8)
+    accum, count = renderer.read_accumulation()
+    for tonemapper in (host_api.TONEMAPPER_ACES, host_api.TONEMAPPER_KHRONOS_PBR_NEUTRAL):
+        renderer.spec.tonemapper = tonemapper
+        path = str(tmp_path / ("display_%d.png" % tonemapper))
+        renderer.save_display_image(path)
+        expected = np.zeros((48, 64, 3), np.uint8)
+        host_api.lib().tonemap_image(expected.ctypes.data_as(C.c_void_p), accum.ctypes.data_as(C.c_void_p), 48 * 64, renderer.spec.exposure, count, tonemapper)
+        assert (np.asarray(Image.open(path)) == expected).all() and expected.max() > 100
+    jpg = str(tmp_path / "s.jpg")
+    renderer.save_screenshot(jpg)
+    ldr = np.clip(accum[..., :3] * (1.0 / count), 0, 1)
+    srgb = (np.where(ldr <= 0.0031308, 12.92 * ldr, 1.055 * ldr ** (1 / 2.4) - 0.055) * 255 + 0.5).astype(np.uint8)
+    # a noisy image: as close to the input as another baseline encoder at the same quality gets
+    other = str(tmp_path / "pil.jpg")
+    Image.fromarray(srgb).save(other, quality=90, subsampling=0)
+    error = np.sqrt(((np.asarray(Image.open(jpg)).astype(float) - srgb) ** 2).mean())
+    assert error < 1.25 * np.sqrt(((np.asarray(Image.open(other)).astype(float) - srgb) ** 2).mean()) + 0.5
+    renderer.close()

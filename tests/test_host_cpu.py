@@ -182,3 +182,86 @@ def test_frame_slices_partition_the_sample_set():
             assert sorted(covered) == list(range(2696, 2696 + total))
     with pytest.raises(ValueError):
         multi_gpu.frame_slice(4, 4, 0, 10)
+
+
+def test_write_jpg_decodes_close_to_input(tmp_path):
+    from PIL import Image
+    y, x = np.mgrid[0:45, 0:70]
+    rgb = np.stack([(x * 3) % 256, (y * 5) % 256, (x + y) * 2 % 256], axis=2).astype(np.uint8)
+    rgb[10:30, 20:50] = (200, 30, 60)
+    path = str(tmp_path / "a.jpg")
+    assert host_api.lib().write_jpg(os.fsencode(path), 70, 45, rgb.ctypes.data_as(C.c_void_p), 90) == 0
+    image = Image.open(path)
+    assert image.size == (70, 45) and image.mode == "RGB"
+    decoded = np.asarray(image).astype(int)
+    assert np.abs(decoded - rgb)[16:24, 24:40].max() <= 3  # blocks that lie inside the flat area
+    assert np.sqrt(((decoded - rgb) ** 2).mean()) < 3.0
+    low = str(tmp_path / "b.jpg")
+    assert host_api.lib().write_jpg(os.fsencode(low), 70, 45, rgb.ctypes.data_as(C.c_void_p), 20) == 0
+    assert os.path.getsize(low) < os.path.getsize(path)
+    assert host_api.lib().write_jpg(os.fsencode(str(tmp_path / "no" / "c.jpg")), 70, 45, rgb.ctypes.data_as(C.c_void_p), 90) != 0
+
+
+def _tonemap_expected(hdr, exposure, count, tonemapper):
+    """tonemap.frag.glsl:17-82 in float64."""
+    color = hdr[:3].astype(np.float64) * (exposure / count)
+    if tonemapper == 0:
+        color = np.clip(color, 0.0, 1.0)
+    elif tonemapper == 1:
+        aces_in = np.array([[0.59719, 0.35458, 0.04823], [0.07600, 0.90834, 0.01566], [0.02840, 0.13383, 0.83777]])
+        aces_out = np.array([[1.60475, -0.53108, -0.07367], [-0.10208, 1.10813, -0.00605], [-0.00327, -0.07276, 1.07602]])
+        v = aces_in @ color
+        color = aces_out @ ((v * (v + 0.0245786) - 0.000090537) / (v * (0.983729 * v + 0.4329510) + 0.238081))
+    elif tonemapper == 2:
+        darkest = color.min()
+        color = color - (darkest - 6.25 * darkest * darkest if darkest < 0.08 else 0.04)
+        brightest = color.max()
+        if brightest >= 0.76:
+            compressed = 0.24
+            new_brightest = 1.0 - compressed * compressed / (brightest + compressed - 0.76)
+            color = color * (new_brightest / brightest)
+            weight = 1.0 - 1.0 / (0.15 * (brightest - new_brightest) + 1.0)
+            color = color * (1.0 - weight) + new_brightest * weight
+    if np.isnan(hdr).any():
+        color = np.array([1.0, 0.0, 1.0])
+    if np.isinf(hdr).any():
+        color = np.array([1.0, 0.0, 0.0])
+    return color
+
+
+def test_tonemappers_match_the_shader_formulas():
+    rng = np.random.default_rng(11)
+    pixels = np.concatenate([rng.uniform(0.0, 0.2, (50, 4)), rng.uniform(0.0, 30.0, (50, 4)), rng.uniform(0.0, 600.0, (20, 4))]).astype(np.float32)
+    pixels[:, 3] = 7.0
+    pixels = np.concatenate([pixels, np.array([[np.nan, 1, 1, 7], [1, np.inf, 1, 7], [np.nan, np.inf, 0, 7], [0, 0, 0, 7]], np.float32)])
+    for tonemapper in (host_api.TONEMAPPER_CLAMP, host_api.TONEMAPPER_ACES, host_api.TONEMAPPER_KHRONOS_PBR_NEUTRAL):
+        for hdr in pixels:
+            out = np.zeros(3, np.float32)
+            host_api.lib().tonemap_pixel(out.ctypes.data_as(C.POINTER(C.c_float)), hdr.ctypes.data_as(C.POINTER(C.c_float)), 1.5, 7, tonemapper)
+            expected = _tonemap_expected(hdr, 1.5, 7, tonemapper)
+            np.testing.assert_allclose(out, expected, rtol=2e-5, atol=2e-6)
+        image = np.zeros((len(pixels), 3), np.uint8)
+        host_api.lib().tonemap_image(image.ctypes.data_as(C.c_void_p), pixels.ctypes.data_as(C.c_void_p), len(pixels), 1.5, 7, tonemapper)
+        linear = np.clip(np.array([_tonemap_expected(hdr, 1.5, 7, tonemapper) for hdr in pixels]), 0.0, 1.0)
+        srgb = np.where(linear <= 0.0031308, 12.92 * linear, 1.055 * linear ** (1.0 / 2.4) - 0.055)
+        assert np.abs(image.astype(int) - (srgb * 255.0 + 0.5).astype(int)).max() <= 1
+    assert tuple(image[-4]) == (255, 0, 255) and tuple(image[-3]) == (255, 0, 0) and tuple(image[-2]) == (255, 0, 0)
+
+
+def test_slides_table():
+    """The 44 slides of src/slides.c: 14 single views and three series of ten path lengths."""
+    show = host_api.Slideshow()
+    assert host_api.lib().create_slides(C.byref(show)) == 44 and show.slide_count == 44
+    first, hdr, cornell = show.slides[0], show.slides[13], show.slides[24 + 3]
+    assert first.quicksave == b"data/saves/bistro/pretty.rt_save" and first.screenshot_frame == 2048
+    assert (first.render_settings.sampling_strategy, first.render_settings.path_length) == (3, 4)
+    assert first.screenshot_path == b"renders/pretty_bistro.png" and first.screenshot_format == host_api.IMAGE_FILE_FORMAT_PNG
+    assert hdr.screenshot_format == host_api.IMAGE_FILE_FORMAT_HDR and hdr.screenshot_frame == 1
+    assert cornell.quicksave == b"data/saves/cornell_box/default.rt_save" and cornell.render_settings.path_length == 3
+    assert cornell.screenshot_path == b"renders/cornell_box_path_lengths/3.png" and cornell.screenshot_frame == 2048
+    assert show.slides[5].render_settings.sampling_strategy == 0 and show.slides[6].render_settings.sampling_strategy == 1
+    assert show.slides[14].screenshot_frame == 16 * 2048 and show.slides[43].quicksave == b"data/saves/living_room/day.rt_save"
+    show.slide_begin, show.slide_end = 0, 45
+    assert host_api.lib().run_slideshow(C.byref(show), 0, b".", b".", 64, 64, 0, 1) != 0  # past the end: refused before any GPU work
+    host_api.lib().free_slideshow(C.byref(show))
+    assert show.slide_count == 0

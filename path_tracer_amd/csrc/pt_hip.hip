@@ -16,6 +16,10 @@
 #include "pt_trace.h"
 #include "pt_shade.h"
 #include "pt_trace_wave.h"
+
+#ifndef PT_BATCH_TARGET_PATHS
+#define PT_BATCH_TARGET_PATHS (64ull << 20)
+#endif
 #include "../../include/pt_hip.h"
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -727,7 +731,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 			break;
 		uint64_t n = s->triangle_count;
 		if (pt_alloc(&s->positions, 3 * n) || pt_alloc(&s->normals_uvs, 3 * n) || pt_alloc(&s->materials, n)
-			|| pt_alloc(&s->counters, PT_COUNTER_WORDS + PT_FETCH_WORDS) || pt_alloc(&s->constants, 1) || pt_alloc(&s->visit_counters, 16)
+			|| pt_alloc(&s->counters, PT_COUNTER_WORDS + PT_FETCH_WORDS) || pt_alloc(&s->constants, 1) || pt_alloc(&s->visit_counters, PT_VISIT_COUNTERS)
 			|| pt_alloc(&s->srgb_to_linear, 256) || pt_alloc(&s->lights, 1))
 			break;
 		if (n) {
@@ -736,7 +740,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 				|| hipMemcpyAsync(s->materials, material_indices, n, hipMemcpyHostToDevice, s->stream) != hipSuccess)
 				break;
 		}
-		if (hipMemsetAsync(s->visit_counters, 0, 16 * sizeof(unsigned long long), s->stream) != hipSuccess)
+		if (hipMemsetAsync(s->visit_counters, 0, PT_VISIT_COUNTERS * sizeof(unsigned long long), s->stream) != hipSuccess)
 			break;
 		// sRGB decoding table for VK_FORMAT_BC1_RGB_SRGB_BLOCK textures
 		float table[256];
@@ -860,8 +864,12 @@ extern "C" int pt_create_render_targets(pt_scene_t* s, uint32_t width, uint32_t 
 	l.tiles_x = (width + PT_TILE - 1) / PT_TILE;
 	l.tiles_y = (height + PT_TILE - 1) / PT_TILE;
 	l.paths_per_frame = l.tiles_x * l.tiles_y * 64;
-	// Enough paths per batch to fill the chip several times over
-	const uint64_t target_paths = 4ull << 20;
+	// A traversal launch keeps 256 K lanes busy until the last one has finished
+	// its last ray; the fewer rays a lane sees per launch, the more of the launch
+	// is that tail. 64 M paths (11 GB of queues) give every lane hundreds of rays.
+	uint64_t target_paths = PT_BATCH_TARGET_PATHS;
+	if (const char* override = getenv("PT_BATCH_PATHS"))
+		target_paths = strtoull(override, NULL, 10);
 	s->max_frames_per_batch = (uint32_t) ((target_paths + l.paths_per_frame - 1) / l.paths_per_frame);
 	if (s->max_frames_per_batch < 1) s->max_frames_per_batch = 1;
 	if (s->max_frames_per_batch > 64) s->max_frames_per_batch = 64;
@@ -1045,7 +1053,7 @@ extern "C" int pt_get_statistics(pt_scene_t* s, pt_statistics_t* out) {
 		return 1;
 	if (pt_synchronize(s))
 		return 1;
-	unsigned long long visits[16];
+	unsigned long long visits[PT_VISIT_COUNTERS];
 	PT_CHECK(hipMemcpy(visits, s->visit_counters, sizeof(visits), hipMemcpyDeviceToHost));
 	s->stats.nodes_visited[0] = visits[0];
 	s->stats.triangles_tested[0] = visits[1];
@@ -1053,7 +1061,10 @@ extern "C" int pt_get_statistics(pt_scene_t* s, pt_statistics_t* out) {
 	s->stats.triangles_tested[1] = visits[3];
 	s->stats.shaded_hits = visits[4];
 	if (getenv("PT_TRACE_DIAGNOSTICS"))
-		printf("trace diagnostics: extension passes %llu active-lane-passes %llu refills %llu; shadow passes %llu active-lane-passes %llu refills %llu\n", visits[6], visits[7], visits[10], visits[8], visits[9], visits[12]);
+		for (int k = 0; k != 2; ++k)
+			printf("trace diagnostics (%s): wave passes %llu, lanes holding a ray %.1f%%, refills %llu, passes with a node step %llu (%.1f%% of lanes in them), with a triangle test %llu (%.1f%%)\n",
+				k ? "shadow" : "extension", visits[6 + 2 * k], 100.0 * (double) visits[7 + 2 * k] / (64.0 * (double) visits[6 + 2 * k]), visits[10 + 2 * k],
+				visits[16 + 2 * k], 100.0 * (double) visits[2 * k] / (64.0 * (double) visits[16 + 2 * k]), visits[17 + 2 * k], 100.0 * (double) visits[1 + 2 * k] / (64.0 * (double) visits[17 + 2 * k]));
 	*out = s->stats;
 	return 0;
 }
@@ -1064,7 +1075,7 @@ extern "C" int pt_reset_statistics(pt_scene_t* s) {
 	if (pt_synchronize(s))
 		return 1;
 	memset(&s->stats, 0, sizeof(s->stats));
-	PT_CHECK(hipMemset(s->visit_counters, 0, 16 * sizeof(unsigned long long)));
+	PT_CHECK(hipMemset(s->visit_counters, 0, PT_VISIT_COUNTERS * sizeof(unsigned long long)));
 	return 0;
 }
 

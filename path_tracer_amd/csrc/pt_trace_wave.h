@@ -29,6 +29,7 @@
 
 #define PT_TRACE_BLOCK 1024   // threads per workgroup of the traversal kernels
 #define PT_WAVES_PER_BLOCK 16
+#define PT_VISIT_COUNTERS 24 // 64-bit words of visit counters and diagnostics
 #define PT_WAVE_STACK 6      // stack entries per lane kept in LDS
 #define PT_CACHE_WORDS 7168  // 16-byte words of BVH prefix kept in LDS (112 KB)
 #ifndef PT_REFILL_MIN
@@ -130,6 +131,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	float idx = 0.0f, idy = 0.0f, idz = 0.0f;
 	bool neg_x = false, neg_y = false, neg_z = false;
 	uint32_t octinv = 7;
+	uint32_t swap_mask_1 = 0x55, swap_mask_2 = 0x33, swap_mask_4 = 0x0f;
 	PtRayShear shear;
 	shear.kx = 0; shear.ky = 1; shear.kz = 2;
 	shear.sx = shear.sy = shear.sz = 0.0f;
@@ -142,7 +144,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	ngroup.x = ngroup.y = tgroup.x = tgroup.y = 0;
 	uint32_t sp = 0;
 	uint32_t node_visits = 0, tri_visits = 0;
-	uint32_t pass_count = 0, refill_count = 0;
+	uint32_t pass_count = 0, refill_count = 0, node_pass_count = 0, tri_pass_count = 0;
+	(void) node_pass_count; (void) tri_pass_count;
 	unsigned long long active_lane_passes = 0;
 
 	// Every pass retires, fetches, walks or tests something, so the loop ends
@@ -211,6 +214,9 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 						idx = 1.0f / cdx; idy = 1.0f / cdy; idz = 1.0f / cdz;
 						neg_x = cdx < 0.0f; neg_y = cdy < 0.0f; neg_z = cdz < 0.0f;
 						octinv = 7u - ((neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u));
+						swap_mask_1 = neg_x ? 0u : 0x55u;
+						swap_mask_2 = neg_y ? 0u : 0x33u;
+						swap_mask_4 = neg_z ? 0u : 0x0fu;
 						ngroup.x = 0;
 						ngroup.y = 0x80000000u;
 					}
@@ -222,6 +228,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		if (!rays_remain && __ballot(active) == 0)
 			break;
 
+		if (COUNT_VISITS)
+			node_pass_count += __ballot(active && tgroup.y == 0) != 0;
 		// ---- one node per lane that has no triangles pending ----
 		if (active && tgroup.y == 0) {
 			if (!(ngroup.y & 0xff000000u) && sp != 0) {
@@ -271,6 +279,10 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				uint32_t nqy[2] = { neg_y ? w4.x : w2.z, neg_y ? w4.y : w2.w }, fqy[2] = { neg_y ? w2.z : w4.x, neg_y ? w2.w : w4.y };
 				uint32_t nqz[2] = { neg_z ? w4.z : w3.x, neg_z ? w4.w : w3.y }, fqz[2] = { neg_z ? w3.x : w4.z, neg_z ? w3.y : w4.w };
 				uint32_t meta[2] = { w1.z, w1.w };
+				// A child's meta byte m turns into its bits of the hit mask as
+				// (m >> 5) << (m & 31): the triangles of a leaf child, bit 24 + slot
+				// for an inner child, nothing for an empty slot. No branches: the
+				// eight box tests of a lane run back to back.
 				uint32_t hitmask = 0;
 #pragma unroll
 				for (int i = 0; i != 8; ++i) {
@@ -280,13 +292,19 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bz), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bz);
 					float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
 					float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
-					if (m != 0 && tn <= tf) {
-						if (imask & (1u << i))
-							hitmask |= 1u << (24u + ((uint32_t) i ^ octinv));
-						else
-							hitmask |= (m >> 5) << (m & 31u);
-					}
+					uint32_t bits = (m >> 5) << (m & 31u);
+					hitmask |= (tn <= tf) ? bits : 0u;
 				}
+				// Inner children: from slot order to visiting order (slot ^ octinv),
+				// three conditional swaps of neighbouring bits, pairs and nibbles
+				uint32_t order = hitmask >> 24;
+				uint32_t swap = ((order >> 1) ^ order) & swap_mask_1;
+				order ^= swap | (swap << 1);
+				swap = ((order >> 2) ^ order) & swap_mask_2;
+				order ^= swap | (swap << 2);
+				swap = ((order >> 4) ^ order) & swap_mask_4;
+				order ^= swap | (swap << 4);
+				hitmask = (hitmask & 0x00ffffffu) | (order << 24);
 				ngroup.x = w1.x;
 				ngroup.y = (hitmask & 0xff000000u) | imask;
 				tgroup.x = w1.y;
@@ -294,6 +312,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			}
 		}
 
+		if (COUNT_VISITS)
+			tri_pass_count += __ballot(active && tgroup.y != 0) != 0;
 		// ---- one triangle per lane that has triangles pending ----
 		for (int round = 0; round != PT_TRIS_PER_PASS; ++round)
 		if (active && tgroup.y != 0) {
@@ -331,6 +351,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			atomicAdd(&visit_counters[6], (unsigned long long) pass_count);
 			atomicAdd(&visit_counters[7], active_lane_passes);
 			atomicAdd(&visit_counters[10], (unsigned long long) refill_count);
+			atomicAdd(&visit_counters[16], (unsigned long long) node_pass_count);
+			atomicAdd(&visit_counters[17], (unsigned long long) tri_pass_count);
 		}
 	}
 }

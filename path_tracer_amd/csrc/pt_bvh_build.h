@@ -25,8 +25,8 @@ struct PtBuild {
 	uint32_t* left;
 	uint32_t* right;
 	uint32_t* parent;    // per node (inner and leaf)
-	uint32_t* range_first;
-	uint32_t* range_last;
+	float* wide_cost;    // 8 per inner node: [j-1] = cost of the subtree as at most j children of a wide node
+	uint8_t* wide_choice; // 8 per inner node: [j-1] = 0: one child (a wide node of its own), k: left subtree gets k of the j slots
 	float* box;          // 6 floats per node (inner and leaf)
 	uint32_t* flags;     // per inner node
 	// wide BVH
@@ -159,15 +159,15 @@ PT_FN void pt_build_radix_tree(const PtBuild& b, uint32_t index) {
 	b.right[i] = right;
 	b.parent[left] = index;
 	b.parent[right] = index;
-	b.range_first[i] = (uint32_t) first;
-	b.range_last[i] = (uint32_t) last;
 	if (i == 0)
 		b.parent[0] = 0xffffffffu;
 }
 
+PT_FN void pt_build_wide_cost(const PtBuild& b, uint32_t node);
+
 // Step 4: called once per leaf (sorted position k). Writes the leaf box, then
 // climbs: the second thread to reach an inner node merges its children's
-// boxes. arrive(flag_ptr) must be an atomic increment that returns the old
+// boxes and evaluates the node's wide-collapse costs. arrive(flag_ptr) must be an atomic increment that returns the old
 // value and orders this thread's earlier box stores before it and its later
 // box loads after it (release/acquire at device scope).
 template <typename Arrive>
@@ -190,6 +190,7 @@ PT_FN void pt_build_refit(const PtBuild& b, float pad, uint32_t k, Arrive arrive
 			out[j] = fminf(l[j], r[j]);
 			out[3 + j] = fmaxf(l[j + 3], r[j + 3]);
 		}
+		pt_build_wide_cost(b, parent);
 		parent = b.parent[parent];
 	}
 }
@@ -200,16 +201,77 @@ PT_FN float pt_box_area(const float* box) {
 	return (dx * dy + dy * dz) + dz * dx;
 }
 
-PT_FN uint32_t pt_build_range_size(const PtBuild& b, uint32_t node) {
-	if (node >= b.n - 1)
-		return 1;
-	return b.range_last[node] - b.range_first[node] + 1;
+// Which binary nodes become wide nodes is chosen to minimise the summed
+// surface area of all wide nodes, the expected number of node visits of a
+// random ray (the dynamic programme of Ylitie, Karras and Laine, "Efficient
+// incoherent ray traversal on GPUs through compressed wide BVHs", HPG 2017,
+// section 3.1, for leaves of one triangle). For the subtree below binary node
+// n and 1 <= j <= 8,
+//   cost(n, 1) = area(n) + split(n, 8)                (n becomes a wide node)
+//   split(n, j) = min over 0 < k < j of cost(left, k) + cost(right, j - k)
+//   cost(n, j) = min(cost(n, j - 1), split(n, j))      (n dissolves into its parent's slots)
+// and a triangle costs nothing. Called bottom-up, after both children.
+PT_FN void pt_build_wide_cost(const PtBuild& b, uint32_t node) {
+	uint32_t left = b.left[node], right = b.right[node];
+	float lc[8], rc[8];
+	for (int j = 0; j != 8; ++j) {
+		lc[j] = (left >= b.n - 1) ? 0.0f : b.wide_cost[8 * (uint64_t) left + j];
+		rc[j] = (right >= b.n - 1) ? 0.0f : b.wide_cost[8 * (uint64_t) right + j];
+	}
+	float split[9];
+	uint8_t split_k[9];
+	for (int j = 2; j <= 8; ++j) {
+		float best = INFINITY;
+		int best_k = 1;
+		for (int k = 1; k < j; ++k) {
+			float c = lc[k - 1] + rc[j - k - 1];
+			if (c < best) { best = c; best_k = k; }
+		}
+		split[j] = best;
+		split_k[j] = (uint8_t) best_k;
+	}
+	float* cost = &b.wide_cost[8 * (uint64_t) node];
+	uint8_t* choice = &b.wide_choice[8 * (uint64_t) node];
+	cost[0] = pt_box_area(&b.box[6 * (uint64_t) node]) + split[8];
+	choice[0] = 0;
+	for (int j = 2; j <= 8; ++j) {
+		if (split[j] < cost[j - 2]) { cost[j - 1] = split[j]; choice[j - 1] = split_k[j]; }
+		else { cost[j - 1] = cost[j - 2]; choice[j - 1] = choice[j - 2]; }
+	}
 }
 
-PT_FN uint32_t pt_build_range_first(const PtBuild& b, uint32_t node) {
-	if (node >= b.n - 1)
-		return node - (b.n - 1);
-	return b.range_first[node];
+// The children of the wide node rooted at binary node root, by the choices of
+// pt_build_wide_cost(); returns their number (2 to 8)
+PT_FN uint32_t pt_build_wide_children(const PtBuild& b, uint32_t root, uint32_t children[8]) {
+	uint32_t count = 0;
+	uint32_t stack_node[8], stack_slots[8];
+	uint32_t sp = 0;
+	// The root itself always splits into 8 slots
+	uint8_t k = 0;
+	{
+		// split(root, 8): recompute the k that pt_build_wide_cost() found
+		uint32_t left = b.left[root], right = b.right[root];
+		float best = INFINITY;
+		for (int t = 1; t < 8; ++t) {
+			float lc = (left >= b.n - 1) ? 0.0f : b.wide_cost[8 * (uint64_t) left + t - 1];
+			float rc = (right >= b.n - 1) ? 0.0f : b.wide_cost[8 * (uint64_t) right + 8 - t - 1];
+			if (lc + rc < best) { best = lc + rc; k = (uint8_t) t; }
+		}
+		stack_node[sp] = right; stack_slots[sp++] = 8u - k;
+		stack_node[sp] = left; stack_slots[sp++] = k;
+	}
+	while (sp != 0) {
+		--sp;
+		uint32_t node = stack_node[sp], slots = stack_slots[sp];
+		uint8_t choice = (node >= b.n - 1) ? 0 : b.wide_choice[8 * (uint64_t) node + slots - 1];
+		if (choice == 0)
+			children[count++] = node;
+		else {
+			stack_node[sp] = b.right[node]; stack_slots[sp++] = slots - choice;
+			stack_node[sp] = b.left[node]; stack_slots[sp++] = choice;
+		}
+	}
+	return count;
 }
 
 // Power of two with biased exponent e, and the smallest e such that
@@ -234,33 +296,13 @@ PT_FN void pt_build_collapse(const PtBuild& b, float pad, uint32_t wide_index, A
 	uint32_t children[8];
 	uint32_t count;
 	uint32_t root = b.task_binary[wide_index];
-	if (pt_build_range_size(b, root) <= 3) {
+	if (root >= b.n - 1) {
+		// A scene of one triangle: the root node holds it
 		children[0] = root;
 		count = 1;
 	}
-	else {
-		children[0] = b.left[root];
-		children[1] = b.right[root];
-		count = 2;
-		while (count < 8) {
-			int best = -1;
-			float best_area = -1.0f;
-			for (uint32_t c = 0; c != count; ++c) {
-				if (pt_build_range_size(b, children[c]) <= 3)
-					continue;
-				float area = pt_box_area(&b.box[6 * (uint64_t) children[c]]);
-				if (area > best_area) {
-					best_area = area;
-					best = (int) c;
-				}
-			}
-			if (best < 0)
-				break;
-			uint32_t open = children[best];
-			children[best] = b.left[open];
-			children[count++] = b.right[open];
-		}
-	}
+	else
+		count = pt_build_wide_children(b, root, children);
 	// Node frame
 	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
 	for (uint32_t c = 0; c != count; ++c) {
@@ -314,9 +356,8 @@ PT_FN void pt_build_collapse(const PtBuild& b, float pad, uint32_t wide_index, A
 	for (int s = 0; s != 8; ++s) {
 		if (child_in_slot[s] < 0)
 			continue;
-		uint32_t size = pt_build_range_size(b, children[child_in_slot[s]]);
-		if (size <= 3)
-			tri_count += size;
+		if (children[child_in_slot[s]] >= b.n - 1)
+			++tri_count;
 		else {
 			++inner_count;
 			node.imask |= (uint8_t) (1u << s);
@@ -336,21 +377,19 @@ PT_FN void pt_build_collapse(const PtBuild& b, float pad, uint32_t wide_index, A
 			node.qlo[j][s] = (uint8_t) fminf(fmaxf(qlo, 0.0f), 255.0f);
 			node.qhi[j][s] = (uint8_t) fminf(fmaxf(qhi, 0.0f), 255.0f);
 		}
-		uint32_t size = pt_build_range_size(b, child);
-		if (size <= 3) {
-			uint32_t first = pt_build_range_first(b, child);
-			for (uint32_t t = 0; t != size; ++t) {
-				uint32_t tri = b.order[first + t];
-				PtTri out;
-				const float* v = &b.verts[9 * (uint64_t) tri];
-				for (int j = 0; j != 3; ++j) { out.v0[j] = v[j]; out.v1[j] = v[3 + j]; out.v2[j] = v[6 + j]; }
-				out.prim = tri;
-				out.pad[0] = out.pad[1] = 0;
-				b.tris[node.tri_base + tri_offset + t] = out;
-			}
-			uint32_t unary = (1u << size) - 1u;
-			node.meta[s] = (uint8_t) ((unary << 5) | tri_offset);
-			tri_offset += size;
+		if (child >= b.n - 1) {
+			// A leaf child is one triangle: every triangle has a box of its own
+			// in its parent, so few triangles are tested in vain, and a lane
+			// never holds a backlog of triangle tests
+			uint32_t tri = b.order[child - (b.n - 1)];
+			PtTri out;
+			const float* v = &b.verts[9 * (uint64_t) tri];
+			for (int j = 0; j != 3; ++j) { out.v0[j] = v[j]; out.v1[j] = v[3 + j]; out.v2[j] = v[6 + j]; }
+			out.prim = tri;
+			out.pad[0] = out.pad[1] = 0;
+			b.tris[node.tri_base + tri_offset] = out;
+			node.meta[s] = (uint8_t) (0x20u | tri_offset);
+			++tri_offset;
 		}
 		else {
 			node.meta[s] = (uint8_t) (0x20u | (24u + (uint32_t) s));

@@ -597,7 +597,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 		if (pt_alloc(&b.verts, 9 * (uint64_t) n) || pt_alloc(&b.bounds, 6) || pt_alloc(&b.keys, n) || pt_alloc(&b.order, n)
 			|| pt_alloc(&keys_sorted, n) || pt_alloc(&order_sorted, n)
 			|| pt_alloc(&b.left, n) || pt_alloc(&b.right, n) || pt_alloc(&b.parent, 2 * (uint64_t) n)
-			|| pt_alloc(&b.range_first, n) || pt_alloc(&b.range_last, n) || pt_alloc(&b.box, 12 * (uint64_t) n)
+			|| pt_alloc(&b.wide_cost, 8 * (uint64_t) n) || pt_alloc(&b.wide_choice, 8 * (uint64_t) n) || pt_alloc(&b.box, 12 * (uint64_t) n)
 			|| pt_alloc(&b.flags, n) || pt_alloc(&b.task_binary, max_nodes) || pt_alloc(&b.counters, 2))
 			break;
 		b.nodes = s->nodes;
@@ -657,7 +657,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 	hipEventDestroy(begin);
 	hipEventDestroy(end);
 	hipFree(b.verts); hipFree(b.bounds); hipFree(b.keys); hipFree(b.order); hipFree(keys_sorted); hipFree(order_sorted);
-	hipFree(b.left); hipFree(b.right); hipFree(b.parent); hipFree(b.range_first); hipFree(b.range_last); hipFree(b.box);
+	hipFree(b.left); hipFree(b.right); hipFree(b.parent); hipFree(b.wide_cost); hipFree(b.wide_choice); hipFree(b.box);
 	hipFree(b.flags); hipFree(b.task_binary); hipFree(b.counters); hipFree(sort_temp);
 	s->bvh_info.node_bytes = sizeof(PtNode);
 	s->bvh_info.triangle_bytes = sizeof(PtTri);

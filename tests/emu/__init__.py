@@ -39,6 +39,8 @@ def lib():
         _lib.emu_destroy_scene.argtypes = [C.c_void_p]
         _lib.emu_set_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         _lib.emu_bvh_info.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.emu_binary_tree_cost.restype = C.c_double
+        _lib.emu_binary_tree_cost.argtypes = [C.c_void_p]
         _lib.emu_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.emu_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.emu_render.restype = C.c_uint64

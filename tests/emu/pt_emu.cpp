@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <vector>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 struct EmuStack {
 	u32x2 data[256];
@@ -33,6 +35,7 @@ struct EmuScene {
 	std::vector<PtNode> nodes;
 	std::vector<PtTri> tris;
 	uint32_t node_count, depth, max_stack;
+	double binary_cost = 0.0;
 	uint32_t emission_material_index;
 	PtSceneView view() const {
 		PtSceneView v;
@@ -43,6 +46,99 @@ struct EmuScene {
 		return v;
 	}
 };
+
+// Top-down builder with a binned surface area heuristic, used as a yardstick
+// for the quality of the trees that the GPU builder makes. Fills the same
+// arrays as the radix tree and refit steps.
+struct SahBuilder {
+	PtBuild& b;
+	float pad;
+	uint32_t next_inner = 0;
+	std::vector<float> centroid;
+	SahBuilder(PtBuild& build, float padding) : b(build), pad(padding), centroid(3 * (size_t) build.n) {
+		for (uint32_t t = 0; t != b.n; ++t) {
+			float lo[3], hi[3];
+			pt_tri_box(&b.verts[9 * (size_t) t], 0.0f, lo, hi);
+			for (int j = 0; j != 3; ++j) centroid[3 * (size_t) t + j] = 0.5f * (lo[j] + hi[j]);
+		}
+		for (uint32_t k = 0; k != b.n; ++k) b.order[k] = k;
+	}
+	static void grow(float* box, const float* lo, const float* hi) {
+		for (int j = 0; j != 3; ++j) { box[j] = std::min(box[j], lo[j]); box[3 + j] = std::max(box[3 + j], hi[j]); }
+	}
+	static float area(const float* box) { return (box[3] < box[0]) ? 0.0f : pt_box_area(box); }
+	uint32_t build(uint32_t begin, uint32_t end, uint32_t parent) {
+		if (end - begin == 1) {
+			uint32_t node = b.n - 1 + begin;
+			float lo[3], hi[3];
+			pt_tri_box(&b.verts[9 * (size_t) b.order[begin]], pad, lo, hi);
+			for (int j = 0; j != 3; ++j) { b.box[6 * (size_t) node + j] = lo[j]; b.box[6 * (size_t) node + 3 + j] = hi[j]; }
+			b.parent[node] = parent;
+			return node;
+		}
+		uint32_t node = next_inner++;
+		b.parent[node] = parent;
+		float clo[3] = { INFINITY, INFINITY, INFINITY }, chi[3] = { -INFINITY, -INFINITY, -INFINITY };
+		for (uint32_t k = begin; k != end; ++k)
+			for (int j = 0; j != 3; ++j) { clo[j] = std::min(clo[j], centroid[3 * (size_t) b.order[k] + j]); chi[j] = std::max(chi[j], centroid[3 * (size_t) b.order[k] + j]); }
+		const int BINS = 32;
+		float best_cost = INFINITY;
+		int best_axis = -1, best_bin = 0;
+		for (int axis = 0; axis != 3; ++axis) {
+			float extent = chi[axis] - clo[axis];
+			if (!(extent > 0.0f)) continue;
+			float boxes[BINS][6];
+			uint32_t counts[BINS];
+			for (int i = 0; i != BINS; ++i) { counts[i] = 0; for (int j = 0; j != 3; ++j) { boxes[i][j] = INFINITY; boxes[i][3 + j] = -INFINITY; } }
+			for (uint32_t k = begin; k != end; ++k) {
+				uint32_t t = b.order[k];
+				int bin = std::min(BINS - 1, (int) ((centroid[3 * (size_t) t + axis] - clo[axis]) / extent * BINS));
+				float lo[3], hi[3];
+				pt_tri_box(&b.verts[9 * (size_t) t], 0.0f, lo, hi);
+				grow(boxes[bin], lo, hi);
+				++counts[bin];
+			}
+			float right_area[BINS];
+			uint32_t right_count[BINS];
+			float acc[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
+			uint32_t count = 0;
+			for (int i = BINS - 1; i > 0; --i) { grow(acc, boxes[i], boxes[i] + 3); count += counts[i]; right_area[i] = area(acc); right_count[i] = count; }
+			float left[6] = { INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY };
+			count = 0;
+			for (int i = 1; i != BINS; ++i) {
+				grow(left, boxes[i - 1], boxes[i - 1] + 3);
+				count += counts[i - 1];
+				if (count == 0 || right_count[i] == 0) continue;
+				float cost = area(left) * (float) count + right_area[i] * (float) right_count[i];
+				if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = i; }
+			}
+		}
+		uint32_t mid;
+		if (best_axis < 0)
+			mid = begin + (end - begin) / 2;
+		else {
+			float extent = chi[best_axis] - clo[best_axis];
+			mid = (uint32_t) (std::partition(b.order + begin, b.order + end, [&](uint32_t t) {
+				return std::min(BINS - 1, (int) ((centroid[3 * (size_t) t + best_axis] - clo[best_axis]) / extent * BINS)) < best_bin; }) - b.order);
+			if (mid == begin || mid == end) mid = begin + (end - begin) / 2;
+		}
+		uint32_t l = build(begin, mid, node), r = build(mid, end, node);
+		b.left[node] = l;
+		b.right[node] = r;
+		const float* lb = &b.box[6 * (size_t) l]; const float* rb = &b.box[6 * (size_t) r];
+		for (int j = 0; j != 3; ++j) { b.box[6 * (size_t) node + j] = std::min(lb[j], rb[j]); b.box[6 * (size_t) node + 3 + j] = std::max(lb[3 + j], rb[3 + j]); }
+		return node;
+	}
+};
+
+// Surface area cost of the binary tree: sum over inner nodes of area / root area
+static double binary_tree_cost(const PtBuild& b) {
+	if (b.n < 2) return 0.0;
+	double total = 0.0;
+	double largest = 0.0;
+	for (uint32_t i = 0; i + 1 < b.n; ++i) { double a = pt_box_area(&b.box[6 * (size_t) i]); total += a; largest = std::max(largest, a); }
+	return total / largest;
+}
 
 extern "C" {
 
@@ -93,10 +189,13 @@ EmuScene* emu_create_scene(uint64_t material_count, uint64_t triangle_count, con
 	b.positions = s->positions.data();
 	memcpy(b.factor, factor, 12); memcpy(b.summand, summand, 12);
 	std::vector<float> verts(9 * (size_t) n), box(12 * (size_t) n);
-	std::vector<uint32_t> bounds(6), order(n), left(n), right(n), parent(2 * (size_t) n), range_first(n), range_last(n), flags(n, 0), task_binary(n), counters(2);
+	std::vector<uint32_t> bounds(6), order(n), left(n), right(n), parent(2 * (size_t) n), flags(n, 0), task_binary(n), counters(2);
+	std::vector<float> wide_cost(8 * (size_t) n);
+	std::vector<uint8_t> wide_choice(8 * (size_t) n);
+	b.wide_cost = wide_cost.data(); b.wide_choice = wide_choice.data();
 	std::vector<uint64_t> keys(n);
 	b.verts = verts.data(); b.bounds = bounds.data(); b.keys = keys.data(); b.order = order.data();
-	b.left = left.data(); b.right = right.data(); b.parent = parent.data(); b.range_first = range_first.data(); b.range_last = range_last.data();
+	b.left = left.data(); b.right = right.data(); b.parent = parent.data(); 
 	b.box = box.data(); b.flags = flags.data(); b.nodes = s->nodes.data(); b.tris = s->tris.data(); b.task_binary = task_binary.data(); b.counters = counters.data();
 	for (int j = 0; j != 3; ++j) { bounds[j] = 0xffffffffu; bounds[3 + j] = 0; }
 	for (uint32_t i = 0; i != n; ++i) {
@@ -117,14 +216,31 @@ EmuScene* emu_create_scene(uint64_t material_count, uint64_t triangle_count, con
 		b.keys = keys.data();
 	}
 	for (uint32_t i = 0; i + 1 < n; ++i) pt_build_radix_tree(b, i);
-	// Visit leaves in a scrambled order to exercise the arrival counters
-	for (uint32_t i = 0; i != n; ++i) {
-		uint32_t k = (uint32_t) (((uint64_t) i * 2654435761u) % n);
-		(void) k;
-	}
 	for (uint32_t i = 0; i != n; ++i)
 		pt_build_refit(b, sb.pad, i, [](uint32_t* flag) { return (*flag)++; });
-	counters[0] = 1; counters[1] = 0; task_binary[0] = 0;
+	const char* builder = getenv("PT_EMU_BUILDER");
+	uint32_t root = 0;
+	if (builder && !strcmp(builder, "sah") && n > 1) {
+		SahBuilder sah(b, sb.pad);
+		sah.build(0, n, 0xffffffffu);
+	}
+	s->binary_cost = binary_tree_cost(b);
+	if (builder && !strcmp(builder, "sah") && n > 1) {
+		// Wide-collapse costs for the yardstick tree, children before parents
+		std::vector<uint32_t> walk, post;
+		walk.push_back(root);
+		while (!walk.empty()) {
+			uint32_t node = walk.back();
+			walk.pop_back();
+			if (node >= n - 1) continue;
+			post.push_back(node);
+			walk.push_back(b.left[node]);
+			walk.push_back(b.right[node]);
+		}
+		for (size_t i = post.size(); i-- != 0;)
+			pt_build_wide_cost(b, post[i]);
+	}
+	counters[0] = 1; counters[1] = 0; task_binary[0] = root;
 	uint32_t level_begin = 0, level_end = 1, depth = 0;
 	while (level_begin < level_end) {
 		for (uint32_t i = level_begin; i != level_end; ++i)
@@ -150,6 +266,7 @@ void emu_set_lights(EmuScene* s, const float* lights, uint32_t count) {
 }
 
 void emu_bvh_info(EmuScene* s, uint32_t* out) { out[0] = s->node_count; out[1] = s->depth; out[2] = s->max_stack; }
+double emu_binary_tree_cost(EmuScene* s) { return s->binary_cost; }
 
 void emu_trace_rays(EmuScene* s, const float* origins, const float* directions, uint32_t count, int32_t* triangles, float* tuv, uint8_t* front, uint64_t* visits_out) {
 	uint64_t total[2] = { 0, 0 };

@@ -162,16 +162,37 @@ struct PtTexture {
 	uint64_t mip_offsets[PT_MAX_MIPS];
 };
 
+// What the shading kernels read per texture, small enough that the table of a
+// whole scene (at most 768 textures) stays in the vector L1: the offset of mip
+// 0 in the blob in units of 16 bytes, and log2 width | log2 height << 8 |
+// VkFormat << 16
+PT_FN u32x2 pt_pack_texture(const PtTexture& t) {
+	uint32_t log_w = 0, log_h = 0;
+	while ((1u << log_w) < t.width) ++log_w;
+	while ((1u << log_h) < t.height) ++log_h;
+	u32x2 e;
+	e.x = (uint32_t) (t.mip_offsets[0] >> 4);
+	e.y = log_w | (log_h << 8) | (t.format << 16);
+	return e;
+}
+
+// Everything that shading reads of a triangle, in one 64-byte line: the
+// vertex records of the .vks arrays (src/scene.h:24-38) side by side
+struct PtShadeTri {
+	u32x2 positions[3];
+	u32x2 normals_uvs[3];
+	uint32_t material;
+	uint32_t pad[3];
+};
+
 // Everything a kernel needs to know about the scene
 struct PtSceneView {
 	const PtNode* nodes;
 	const PtTri* tris;
 	uint32_t triangle_count;
-	// mesh data exactly as stored in the .vks file
-	const u32x2* positions;     // 3 per triangle
-	const u32x2* normals_uvs;   // 3 per triangle, 4 x unorm16
+	const PtShadeTri* shade_tris; // mesh data as stored in the .vks file, regrouped per triangle
 	const uint8_t* materials;   // 1 per triangle
-	const PtTexture* textures;  // 3 per material
+	const u32x2* texture_table; // 3 per material, see pt_pack_texture()
 	const uint8_t* texture_blob;
 	const float* srgb_to_linear; // 256 entries
 	const f32x4* lights;

@@ -30,6 +30,9 @@
 static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device constants must agree");
 
 #define PT_BLOCK 256
+#ifndef PT_SHADE_BLOCK
+#define PT_SHADE_BLOCK 256 // threads per workgroup of the shading kernel
+#endif
 #define PT_INVALID 0xffffffffu
 
 #define PT_CHECK(call) do { hipError_t pt_err_ = (call); if (pt_err_ != hipSuccess) { \
@@ -107,14 +110,14 @@ __global__ void __launch_bounds__(PT_BLOCK) k_build_collapse(PtBuild b, uint32_t
 // Blocks are dealt round-robin to the 8 XCDs, each with its own L2. Giving
 // XCD x the x-th contiguous eighth of a queue keeps rays that started as
 // neighbouring pixels on one L2. Returns false for surplus blocks.
-__device__ __forceinline__ bool pt_block_first_slot(uint32_t count, uint32_t* out_first_slot) {
-	uint32_t block_count = (count + PT_BLOCK - 1) / PT_BLOCK;
+__device__ __forceinline__ bool pt_block_first_slot(uint32_t count, uint32_t* out_first_slot, uint32_t block_size = PT_BLOCK) {
+	uint32_t block_count = (count + block_size - 1) / block_size;
 	uint32_t chunk = (block_count + 7) / 8;
 	uint32_t group = blockIdx.x & 7, j = blockIdx.x >> 3;
 	uint32_t virtual_block = group * chunk + j;
 	if (j >= chunk || virtual_block >= block_count)
 		return false;
-	*out_first_slot = virtual_block * PT_BLOCK;
+	*out_first_slot = virtual_block * block_size;
 	return true;
 }
 
@@ -131,6 +134,36 @@ __device__ __forceinline__ uint32_t pt_wave_push(uint32_t* counter, bool want) {
 		base = (uint32_t) __shfl((int) base, (int) leader);
 	}
 	return base + prefix;
+}
+
+// Reserves slots in two queues for the lanes of a whole workgroup with two
+// atomics per workgroup. Counters that every wave of a launch adds to are
+// served one after the other by a single L2 channel, a few nanoseconds each:
+// with one atomic per wave and queue that alone took as long as the shading
+// of 66 M paths. All threads of the workgroup must call this.
+template <uint32_t BLOCK>
+__device__ __forceinline__ void pt_block_push_2(uint32_t* counter_a, bool want_a, uint32_t* counter_b, bool want_b, uint32_t* out_slot_a, uint32_t* out_slot_b) {
+	__shared__ uint32_t wave_offsets[2][BLOCK / 64];
+	__shared__ uint32_t bases[2];
+	const uint32_t wave = threadIdx.x >> 6;
+	unsigned long long mask_a = __ballot(want_a), mask_b = __ballot(want_b);
+	if ((threadIdx.x & 63) == 0) {
+		wave_offsets[0][wave] = (uint32_t) __popcll(mask_a);
+		wave_offsets[1][wave] = (uint32_t) __popcll(mask_b);
+	}
+	__syncthreads();
+	if (threadIdx.x < 2) {
+		uint32_t total = 0;
+		for (uint32_t w = 0; w != BLOCK / 64; ++w) {
+			uint32_t count = wave_offsets[threadIdx.x][w];
+			wave_offsets[threadIdx.x][w] = total;
+			total += count;
+		}
+		bases[threadIdx.x] = total ? atomicAdd(threadIdx.x ? counter_b : counter_a, total) : 0u;
+	}
+	__syncthreads();
+	*out_slot_a = bases[0] + wave_offsets[0][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask_a >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask_a, 0u));
+	*out_slot_b = bases[1] + wave_offsets[1][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask_b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask_b, 0u));
 }
 
 struct PtTraceArgs {
@@ -220,6 +253,21 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_shadow(PtTraceArgs a) 
 		});
 }
 
+// The three .vks arrays of a triangle side by side in one 64-byte record
+__global__ void __launch_bounds__(PT_BLOCK) k_build_shade_tris(const u32x2* positions, const u32x2* normals_uvs, const uint8_t* materials, PtShadeTri* shade_tris, uint32_t triangle_count) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i >= triangle_count)
+		return;
+	PtShadeTri t;
+	for (int v = 0; v != 3; ++v) {
+		t.positions[v] = positions[3 * (uint64_t) i + v];
+		t.normals_uvs[v] = normals_uvs[3 * (uint64_t) i + v];
+	}
+	t.material = materials[i];
+	t.pad[0] = t.pad[1] = t.pad[2] = 0;
+	shade_tris[i] = t;
+}
+
 struct PtShadeArgs {
 	PtSceneView scene;
 	PtWavefront wf;
@@ -231,10 +279,13 @@ struct PtShadeArgs {
 	unsigned long long* visit_counters; // [4] counts shaded hits, or NULL
 };
 
-__global__ void __launch_bounds__(PT_BLOCK) k_shade(PtShadeArgs a) {
+// One instantiation per sampling strategy: the strategy is a compile-time
+// constant inside, so each kernel carries the registers of one estimator only
+template <int STRATEGY>
+__global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(PtShadeArgs a) {
 	uint32_t first_slot;
 	uint32_t count = a.wf.ext_count[a.k - 1];
-	if (!pt_block_first_slot(count, &first_slot))
+	if (!pt_block_first_slot(count, &first_slot, PT_SHADE_BLOCK))
 		return;
 	uint32_t slot = first_slot + threadIdx.x;
 	bool active = slot < count;
@@ -255,7 +306,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(PtShadeArgs a) {
 		uint32_t sx = pt_as_uint(s0.w), sy = pt_as_uint(s1.w);
 		if (a.visit_counters && hit.x != PT_INVALID)
 			atomicAdd(&a.visit_counters[4], 1ull);
-		r = pt_shade_vertex(a.scene, *a.constants, a.strategy, a.path_length, a.k,
+		r = pt_shade_vertex(a.scene, *a.constants, STRATEGY, a.path_length, a.k,
 			hit.x, pt_as_float(hit.y), pt_as_float(hit.z), hit.w != 0, mk3(d.x, d.y, d.z),
 			radiance, throughput, nee_throughput, sx, sy);
 		a.wf.radiance[path] = mk4(radiance.x, radiance.y, radiance.z, 0.0f);
@@ -264,13 +315,13 @@ __global__ void __launch_bounds__(PT_BLOCK) k_shade(PtShadeArgs a) {
 			a.wf.state1[path] = mk4(nee_throughput.x, nee_throughput.y, nee_throughput.z, pt_as_float(sy));
 		}
 	}
-	// Compact survivors into the next queues (whole waves take part)
-	uint32_t next_slot = pt_wave_push(&a.wf.ext_count[a.k], r.continues);
+	// Compact survivors into the next queues (the whole workgroup takes part)
+	uint32_t next_slot, shadow_slot;
+	pt_block_push_2<PT_SHADE_BLOCK>(&a.wf.ext_count[a.k], r.continues, &a.wf.shadow_count[a.k], r.shadow, &next_slot, &shadow_slot);
 	if (r.continues) {
 		a.wf.ray_o[a.parity ^ 1][next_slot] = mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path));
 		a.wf.ray_d[a.parity ^ 1][next_slot] = mk4(r.next_dir.x, r.next_dir.y, r.next_dir.z, 0.0f);
 	}
-	uint32_t shadow_slot = pt_wave_push(&a.wf.shadow_count[a.k], r.shadow);
 	if (r.shadow) {
 		a.wf.sh_o[shadow_slot] = mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path));
 		a.wf.sh_d[shadow_slot] = mk4(r.shadow_dir.x, r.shadow_dir.y, r.shadow_dir.z, r.shadow_factor);
@@ -388,9 +439,11 @@ struct pt_scene {
 	hipStream_t stream;
 	// scene data
 	uint32_t triangle_count, material_count, texture_count;
-	u32x2* positions;
-	u32x2* normals_uvs;
+	u32x2* positions;     // only until the BVH and the shading records are built
+	u32x2* normals_uvs;   // likewise
+	PtShadeTri* shade_tris;
 	uint8_t* materials;
+	u32x2* texture_table;
 	PtTexture* textures;
 	uint8_t* texture_blob;
 	float* srgb_to_linear;
@@ -410,7 +463,7 @@ struct pt_scene {
 	f32x4* accum;
 	uint32_t sample_count;
 	PtWavefront wf;
-	uint32_t* counters; // ext_count[PT_MAX_PATH_LENGTH + 1], shadow_count[PT_MAX_PATH_LENGTH + 1]
+	uint32_t* counters; // ext_count[], shadow_count[] at PT_SHADOW_COUNT_OFFSET, then the fetch counters
 	PtConstants* constants;
 	u32x2* stack_overflow;
 	uint32_t stack_capacity, stack_overflow_stride;
@@ -431,13 +484,16 @@ struct pt_scene {
 };
 
 // ext_count[k] and shadow_count[k] per bounce, then 8 fetch counters for each of the possible trace launches of a batch
-#define PT_COUNTER_WORDS (2 * (PT_MAX_PATH_LENGTH + 1))
+// The two families sit on different 128-byte lines: both are targets of atomics in one launch
+#define PT_SHADOW_COUNT_OFFSET 32
+#define PT_COUNTER_WORDS (2 * PT_SHADOW_COUNT_OFFSET)
+static_assert(PT_MAX_PATH_LENGTH + 1 <= PT_SHADOW_COUNT_OFFSET, "queue counters overlap");
 #define PT_FETCH_WORDS (8 * PT_FETCH_STRIDE * PT_COUNTER_WORDS)
 
 static uint32_t pt_grid(uint64_t count) { return (uint32_t) ((count + PT_BLOCK - 1) / PT_BLOCK); }
 // Grid for kernels that use pt_block_first_slot(): a multiple of 8 blocks
-static uint32_t pt_grid_chunked(uint64_t capacity) {
-	uint32_t blocks = pt_grid(capacity);
+static uint32_t pt_grid_chunked(uint64_t capacity, uint32_t block_size = PT_BLOCK) {
+	uint32_t blocks = (uint32_t) ((capacity + block_size - 1) / block_size);
 	uint32_t chunk = (blocks + 7) / 8;
 	return chunk ? 8 * chunk : 8;
 }
@@ -447,10 +503,9 @@ static PtSceneView pt_scene_view(const pt_scene* s) {
 	v.nodes = s->nodes;
 	v.tris = s->tris;
 	v.triangle_count = s->triangle_count;
-	v.positions = s->positions;
-	v.normals_uvs = s->normals_uvs;
+	v.shade_tris = s->shade_tris;
 	v.materials = s->materials;
-	v.textures = s->textures;
+	v.texture_table = s->texture_table;
 	v.texture_blob = s->texture_blob;
 	v.srgb_to_linear = s->srgb_to_linear;
 	v.lights = s->lights;
@@ -510,7 +565,7 @@ static void pt_collect(pt_scene* s) {
 			s->stats.extension_rays -= s->pending_counter_reads[i].padding_paths;
 		for (uint32_t k = 0; k <= PT_MAX_PATH_LENGTH; ++k) {
 			s->stats.extension_rays += c[k];
-			s->stats.shadow_rays += c[PT_MAX_PATH_LENGTH + 1 + k];
+			s->stats.shadow_rays += c[PT_SHADOW_COUNT_OFFSET + k];
 		}
 		hipHostFree(c);
 	}
@@ -708,7 +763,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 	s->triangle_count = (uint32_t) header->triangle_count;
 	s->material_count = (uint32_t) header->material_count;
 	s->texture_count = texture_count;
-	s->positions = NULL; s->normals_uvs = NULL; s->materials = NULL; s->textures = NULL; s->texture_blob = NULL;
+	s->positions = NULL; s->normals_uvs = NULL; s->shade_tris = NULL; s->materials = NULL; s->textures = NULL; s->texture_table = NULL; s->texture_blob = NULL;
 	s->srgb_to_linear = NULL; s->lights = NULL; s->light_count = 0; s->nodes = NULL; s->tris = NULL;
 	memset(&s->bvh_info, 0, sizeof(s->bvh_info));
 	s->strategy = PT_STRATEGY_NEE;
@@ -730,7 +785,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 		if (hipStreamCreate(&s->stream) != hipSuccess)
 			break;
 		uint64_t n = s->triangle_count;
-		if (pt_alloc(&s->positions, 3 * n) || pt_alloc(&s->normals_uvs, 3 * n) || pt_alloc(&s->materials, n)
+		if (pt_alloc(&s->positions, 3 * n) || pt_alloc(&s->normals_uvs, 3 * n) || pt_alloc(&s->shade_tris, n) || pt_alloc(&s->materials, n)
 			|| pt_alloc(&s->counters, PT_COUNTER_WORDS + PT_FETCH_WORDS) || pt_alloc(&s->constants, 1) || pt_alloc(&s->visit_counters, PT_VISIT_COUNTERS)
 			|| pt_alloc(&s->srgb_to_linear, 256) || pt_alloc(&s->lights, 1))
 			break;
@@ -768,14 +823,30 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 			for (uint32_t m = 0; m != textures[i].mip_count; ++m)
 				if (textures[i].mip_data[m])
 					memcpy(&blob[descs[i].mip_offsets[m]], textures[i].mip_data[m], textures[i].mip_sizes[m]);
-		if (pt_alloc(&s->texture_blob, blob.size()) || pt_alloc(&s->textures, descs.size()))
+		std::vector<u32x2> packed(descs.size());
+		for (size_t i = 0; i != descs.size(); ++i)
+			packed[i] = (i < texture_count) ? pt_pack_texture(descs[i]) : u32x2{ 0u, 0u };
+		if (blob.size() >> 36) {
+			printf("The textures take %llu bytes, more than the 64 GiB that a scene may hold.\n", (unsigned long long) blob.size());
+			break;
+		}
+		if (pt_alloc(&s->texture_blob, blob.size()) || pt_alloc(&s->textures, descs.size()) || pt_alloc(&s->texture_table, packed.size()))
 			break;
 		if (hipMemcpyAsync(s->texture_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream) != hipSuccess
 			|| hipMemcpyAsync(s->textures, descs.data(), descs.size() * sizeof(PtTexture), hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(s->texture_table, packed.data(), packed.size() * sizeof(u32x2), hipMemcpyHostToDevice, s->stream) != hipSuccess
 			|| hipStreamSynchronize(s->stream) != hipSuccess)
 			break;
 		if (pt_build_bvh(s, header))
 			break;
+		// Regroup the vertex arrays per triangle for shading; the arrays
+		// themselves are not needed any more
+		if (n)
+			hipLaunchKernelGGL(k_build_shade_tris, dim3(pt_grid((uint32_t) n)), dim3(PT_BLOCK), 0, s->stream, s->positions, s->normals_uvs, s->materials, s->shade_tris, (uint32_t) n);
+		if (hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+			break;
+		hipFree(s->positions); s->positions = NULL;
+		hipFree(s->normals_uvs); s->normals_uvs = NULL;
 		// The traversal kernels are persistent: one workgroup of sixteen waves per CU
 		int cu_count = 0;
 		if (hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, device_index) != hipSuccess || cu_count <= 0)
@@ -808,7 +879,7 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 	for (size_t i = 0; i != s->event_pool.size(); ++i)
 		hipEventDestroy(s->event_pool[i]);
 	pt_free_render_targets(s);
-	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->materials); hipFree(s->textures); hipFree(s->texture_blob);
+	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->shade_tris); hipFree(s->materials); hipFree(s->textures); hipFree(s->texture_table); hipFree(s->texture_blob);
 	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->nodes); hipFree(s->tris);
 	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters); hipFree(s->stack_overflow);
 	if (s->stream)
@@ -893,7 +964,7 @@ static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity, 
 	a.bounce = bounce;
 	a.parity = parity;
 	a.cache_layout = pt_cache_layout(s->bvh_info.node_count, s->bvh_info.triangle_count);
-	a.fetch = s->counters + PT_COUNTER_WORDS + 8 * PT_FETCH_STRIDE * (shadow ? PT_MAX_PATH_LENGTH + 1 + bounce : bounce);
+	a.fetch = s->counters + PT_COUNTER_WORDS + 8 * PT_FETCH_STRIDE * (shadow ? PT_SHADOW_COUNT_OFFSET + bounce : bounce);
 	a.visit_counters = s->visit_counters_enabled ? s->visit_counters : NULL;
 	return a;
 }
@@ -915,7 +986,7 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 	batch.frame_stride = frame_stride;
 	uint32_t path_count = batch.paths_per_frame * frame_count;
 	s->wf.ext_count = s->counters;
-	s->wf.shadow_count = s->counters + PT_MAX_PATH_LENGTH + 1;
+	s->wf.shadow_count = s->counters + PT_SHADOW_COUNT_OFFSET;
 	PT_CHECK(hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * (PT_COUNTER_WORDS + PT_FETCH_WORDS), s->stream));
 	{
 		pt_launch_timer timer(s, PT_K_RAYGEN);
@@ -935,7 +1006,12 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 			a.k = k;
 			a.parity = parity;
 			a.visit_counters = s->visit_counters_enabled ? s->visit_counters : NULL;
-			hipLaunchKernelGGL(k_shade, dim3(pt_grid_chunked(path_count)), dim3(PT_BLOCK), 0, s->stream, a);
+			switch (a.strategy) {
+			case PT_STRATEGY_SPHERICAL: hipLaunchKernelGGL(k_shade<PT_STRATEGY_SPHERICAL>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
+			case PT_STRATEGY_PSA: hipLaunchKernelGGL(k_shade<PT_STRATEGY_PSA>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
+			case PT_STRATEGY_BRDF: hipLaunchKernelGGL(k_shade<PT_STRATEGY_BRDF>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
+			default: hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
+			}
 		}
 		if (s->strategy == PT_STRATEGY_NEE && k < s->path_length) {
 			pt_launch_timer timer(s, PT_K_TRACE_SHADOW);
@@ -1112,7 +1188,7 @@ extern "C" int pt_trace_primary_rays(pt_scene_t* s, const pt_constants_t* consta
 		if (pt_alloc(&d_triangles, pixels) || pt_alloc(&d_barycentrics, 2 * pixels) || pt_alloc(&d_front, pixels))
 			break;
 		s->wf.ext_count = s->counters;
-		s->wf.shadow_count = s->counters + PT_MAX_PATH_LENGTH + 1;
+		s->wf.shadow_count = s->counters + PT_SHADOW_COUNT_OFFSET;
 		if (hipMemcpyAsync(s->constants, constants, sizeof(PtConstants), hipMemcpyHostToDevice, s->stream) != hipSuccess
 			|| hipMemsetAsync(s->counters, 0, sizeof(uint32_t) * (PT_COUNTER_WORDS + PT_FETCH_WORDS), s->stream) != hipSuccess)
 			break;

@@ -177,27 +177,28 @@ PT_FN uint32_t pt_decode_bc4(uint32_t w0, uint32_t w1, uint32_t px, uint32_t py)
 
 // Mip payloads start on 16-byte boundaries of the blob, so blocks can be
 // read with aligned 8- and 16-byte loads
-PT_FN v3 pt_fetch_texel(const PtSceneView& s, const PtTexture& t, int32_t x, int32_t y) {
-	uint32_t ux = (uint32_t) x & (t.width - 1), uy = (uint32_t) y & (t.height - 1);
-	uint32_t blocks_x = (t.width + 3) / 4;
-	uint64_t block = (uint64_t) (uy / 4) * blocks_x + ux / 4;
-	if (t.format == 141) {
-		u32x4 w = *(const u32x4*) (s.texture_blob + t.mip_offsets[0] + block * 16);
+PT_FN v3 pt_fetch_texel(const PtSceneView& s, u32x2 t, int32_t x, int32_t y) {
+	uint32_t log_w = t.y & 0xffu, log_h = (t.y >> 8) & 0xffu, format = t.y >> 16;
+	uint32_t ux = (uint32_t) x & ((1u << log_w) - 1u), uy = (uint32_t) y & ((1u << log_h) - 1u);
+	uint64_t block = ((uint64_t) (uy / 4) << (log_w - 2)) + ux / 4;
+	const uint8_t* mip_0 = s.texture_blob + ((uint64_t) t.x << 4);
+	if (format == 141) {
+		u32x4 w = *(const u32x4*) (mip_0 + block * 16);
 		uint32_t r = pt_decode_bc4(w.x, w.y, ux & 3, uy & 3);
 		uint32_t g = pt_decode_bc4(w.z, w.w, ux & 3, uy & 3);
 		return mk3((float) r / 255.0f, (float) g / 255.0f, 0.0f);
 	}
-	u32x2 w = *(const u32x2*) (s.texture_blob + t.mip_offsets[0] + block * 8);
+	u32x2 w = *(const u32x2*) (mip_0 + block * 8);
 	uint32_t r, g, b;
 	pt_decode_bc1(w.x, w.y, ux & 3, uy & 3, &r, &g, &b);
-	if (t.format == 132)
+	if (format == 132)
 		return mk3(s.srgb_to_linear[r], s.srgb_to_linear[g], s.srgb_to_linear[b]);
 	return mk3((float) r / 255.0f, (float) g / 255.0f, (float) b / 255.0f);
 }
 
 PT_FN v3 pt_sample_texture(const PtSceneView& s, uint32_t texture_index, v2 uv) {
-	const PtTexture& t = s.textures[texture_index];
-	float x = uv.x * (float) t.width - 0.5f, y = uv.y * (float) t.height - 0.5f;
+	u32x2 t = s.texture_table[texture_index];
+	float x = uv.x * (float) (1u << (t.y & 0xffu)) - 0.5f, y = uv.y * (float) (1u << ((t.y >> 8) & 0xffu)) - 0.5f;
 	float fx0 = floorf(x), fy0 = floorf(y);
 	float wx = x - fx0, wy = y - fy0;
 	int32_t x0 = (int32_t) fx0, y0 = (int32_t) fy0;
@@ -226,10 +227,14 @@ PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants&
 	s.pos = mk3(0.0f, 0.0f, 0.0f);
 	v3 normal_geo = mk3(0.0f, 0.0f, 0.0f);
 	v2 tc = mk2(0.0f, 0.0f);
+	// One 64-byte line holds all of the triangle
+	const u32x4* record = (const u32x4*) &scene.shade_tris[triangle_index];
+	u32x4 r0 = record[0], r1 = record[1], r2 = record[2], r3 = record[3];
+	u32x2 vertex_positions[3] = { { r0.x, r0.y }, { r0.z, r0.w }, { r1.x, r1.y } };
+	u32x2 vertex_normals_uvs[3] = { { r1.z, r1.w }, { r2.x, r2.y }, { r2.z, r2.w } };
 	for (int i = 0; i != 3; ++i) {
-		uint64_t vert = (uint64_t) triangle_index * 3 + i;
-		u32x2 qp = scene.positions[vert];
-		u32x2 qn = scene.normals_uvs[vert];
+		u32x2 qp = vertex_positions[i];
+		u32x2 qn = vertex_normals_uvs[i];
 		float n0 = (float) (qn.x & 0xffffu) / 65535.0f, n1 = (float) (qn.x >> 16) / 65535.0f;
 		float t0 = (float) (qn.y & 0xffffu) / 65535.0f, t1 = (float) (qn.y >> 16) / 65535.0f;
 		poss[i] = pt_dequantize_position(qp, c.dequantization_factor, c.dequantization_summand);
@@ -240,7 +245,7 @@ PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants&
 		tc.y += barys[i] * tcs[i].y;
 	}
 	normal_geo = normalize(normal_geo);
-	uint32_t material = scene.materials[triangle_index];
+	uint32_t material = r3.x;
 	v3 base_color = pt_sample_texture(scene, 3 * material + 0, tc);
 	v3 specular = pt_sample_texture(scene, 3 * material + 1, tc);
 	v3 normal_tex = pt_sample_texture(scene, 3 * material + 2, tc);

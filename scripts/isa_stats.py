@@ -7,7 +7,7 @@ import sys
 listing, needle = sys.argv[1], sys.argv[2]
 lines = open(listing).read().split("\n")
 start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\S*:", l) and needle in l and "rocprim" not in l)
-end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
+end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
 body = lines[start:end + 1]
 if "--dump" in sys.argv:
     open(sys.argv[sys.argv.index("--dump") + 1], "w").write("\n".join(body))

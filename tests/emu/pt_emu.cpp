@@ -29,6 +29,8 @@ struct EmuScene {
 	std::vector<u32x2> positions, normals_uvs;
 	std::vector<uint8_t> materials;
 	std::vector<PtTexture> textures;
+	std::vector<u32x2> texture_table;
+	std::vector<PtShadeTri> shade_tris;
 	std::vector<uint8_t> blob;
 	std::vector<float> srgb;
 	std::vector<f32x4> lights;
@@ -40,8 +42,8 @@ struct EmuScene {
 	PtSceneView view() const {
 		PtSceneView v;
 		v.nodes = nodes.data(); v.tris = tris.data(); v.triangle_count = n;
-		v.positions = positions.data(); v.normals_uvs = normals_uvs.data(); v.materials = materials.data();
-		v.textures = textures.data(); v.texture_blob = blob.data(); v.srgb_to_linear = srgb.data();
+		v.shade_tris = shade_tris.data(); v.materials = materials.data();
+		v.texture_table = texture_table.data(); v.texture_blob = blob.data(); v.srgb_to_linear = srgb.data();
 		v.lights = lights.data(); v.light_count = (uint32_t) lights.size(); v.emission_material_index = emission_material_index;
 		return v;
 	}
@@ -174,6 +176,17 @@ EmuScene* emu_create_scene(uint64_t material_count, uint64_t triangle_count, con
 		}
 	}
 	s->blob.resize(s->blob.size() + 16);
+	s->texture_table.resize(s->textures.size());
+	for (uint32_t i = 0; i != texture_count; ++i)
+		s->texture_table[i] = pt_pack_texture(s->textures[i]);
+	// As k_build_shade_tris() of pt_hip.hip
+	s->shade_tris.resize((size_t) n + 1);
+	for (uint32_t i = 0; i != n; ++i) {
+		PtShadeTri& t = s->shade_tris[i];
+		for (int v = 0; v != 3; ++v) { t.positions[v] = s->positions[3 * (size_t) i + v]; t.normals_uvs[v] = s->normals_uvs[3 * (size_t) i + v]; }
+		t.material = materials[i];
+		t.pad[0] = t.pad[1] = t.pad[2] = 0;
+	}
 	s->emission_material_index = 0;
 	s->nodes.resize(n ? n : 1);
 	s->tris.resize(n ? n : 1);

@@ -851,7 +851,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 		int cu_count = 0;
 		if (hipDeviceGetAttribute(&cu_count, hipDeviceAttributeMultiprocessorCount, device_index) != hipSuccess || cu_count <= 0)
 			break;
-		s->trace_grid = ((uint32_t) cu_count + 7) & ~7u;
+		s->trace_grid = (((uint32_t) cu_count + 7) & ~7u) * PT_TRACE_BLOCKS_PER_CU;
 		s->stack_capacity = s->bvh_info.depth + 2;
 		if (s->stack_capacity < PT_WAVE_STACK + 1)
 			s->stack_capacity = PT_WAVE_STACK + 1;

@@ -16,13 +16,15 @@
 //   * The traversal stack holds one entry per BVH level (a group of sibling
 //     nodes): PT_WAVE_STACK entries per lane in LDS, laid out entry-major so
 //     that a wave's accesses are conflict-free 8-byte words, the rest in HBM.
-//   * One 1024-thread workgroup owns a whole CU and its 160 KB of LDS. What
-//     the stacks leave free (112 KB) holds a prefix of the BVH: the builder
-//     emits nodes, and the triangles of their leaves, in breadth-first order,
-//     so the prefix is the top of the tree - or all of it for a small scene.
-//     Incoherent rays make every lane of a load instruction touch its own
-//     cache line, which the vector L1 serves at a fraction of its bandwidth;
-//     the same gather from LDS is several times faster and ten times closer.
+//   * Two 1024-thread workgroups share a CU: 32 waves, eight per SIMD, is what
+//     hides the latency of the gathers (58 VGPRs allow it). Each has half of
+//     the 160 KB of LDS. What its stacks leave free (32 KB) holds a prefix of
+//     the BVH: the builder emits nodes, and the triangles of their leaves, in
+//     breadth-first order, so the prefix is the top of the tree - or all of
+//     it for a small scene. Incoherent rays make every lane of a load
+//     instruction touch its own cache line, which the vector L1 serves at a
+//     fraction of its bandwidth; the same gather from LDS is several times
+//     faster and ten times closer.
 #pragma once
 #include "pt_common.h"
 #include "pt_trace.h"
@@ -30,8 +32,14 @@
 #define PT_TRACE_BLOCK 1024   // threads per workgroup of the traversal kernels
 #define PT_WAVES_PER_BLOCK 16
 #define PT_VISIT_COUNTERS 24 // 64-bit words of visit counters and diagnostics
+#ifndef PT_TRACE_BLOCKS_PER_CU
+#define PT_TRACE_BLOCKS_PER_CU 2 // workgroups that share a CU and its LDS: 32 waves, the most a CU holds
+#endif
+#ifndef PT_WAVE_STACK
 #define PT_WAVE_STACK 6      // stack entries per lane kept in LDS
-#define PT_CACHE_WORDS 7168  // 16-byte words of BVH prefix kept in LDS (112 KB)
+#endif
+// 16-byte words of BVH prefix kept in LDS: what the stacks leave of a workgroup's share of 160 KB
+#define PT_CACHE_WORDS ((163840 / PT_TRACE_BLOCKS_PER_CU - PT_WAVES_PER_BLOCK * PT_WAVE_STACK * 512) / 16)
 #ifndef PT_REFILL_MIN
 #define PT_REFILL_MIN 16     // idle lanes that trigger a refill
 #endif
@@ -49,7 +57,7 @@ struct PtWaveLds {
 	u32x2 stack[PT_WAVE_STACK][64];
 };
 
-// All LDS of one CU: 112 KB + 16 * 3 KB = 160 KB
+// The LDS of one workgroup: BVH prefix + 16 * 3 KB of stacks = 160 KB / PT_TRACE_BLOCKS_PER_CU
 struct PtTraceLds {
 	u32x4 cache[PT_CACHE_WORDS];
 	PtWaveLds wave[PT_WAVES_PER_BLOCK];

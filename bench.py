@@ -72,6 +72,17 @@ def trace_bytes_per_ray(kind, nodes_per_ray, tris_per_ray, node_bytes, tri_bytes
     return stream + nodes_per_ray * node_bytes + tris_per_ray * tri_bytes
 
 
+def measured_hbm_traffic(workload, kernel):
+    """HBM bytes per launch of a kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this benchmark, scripts/gpu_pmc.sh + scripts/pmc_to_json.py), or None. Counters cannot be read inside the timed run."""
+    path = os.path.join(ROOT, "profiles", "pmc_current.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as file:
+        entry = json.load(file).get(workload, {}).get("kernels", {}).get(kernel)
+    return entry["hbm_bytes_per_launch"] if entry else None
+
+
 def cpu_baseline(args, threads, root, first_frame_index):
     """The CPU oracle on a bounded sample of the same workload (reported baseline, not the target)."""
     import oracle
@@ -196,7 +207,9 @@ def main():
             "samples_per_s": total_paths / seconds,
             "rays_per_path": total_rays / total_paths,
             "roofline": {"bound": "hbm", "kernel": "k_trace_%s" % dominant, "achieved": d["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": d["achieved_gbs"] / HBM_PEAK_GBS, "traffic": None,
+                         "frac": d["achieved_gbs"] / HBM_PEAK_GBS,
+                         "traffic": measured_hbm_traffic(args.workload, "k_trace_%s<false>" % dominant) if (spp == 32 and not args.triangles) else None,
+                         "algorithmic_bytes_per_launch": d["bytes_per_ray"] * d["rays_per_launch"],
                          "avg_launch_ms": d["avg_ms"], "rays_per_launch": d["rays_per_launch"], "bytes_per_ray": d["bytes_per_ray"],
                          "nodes_per_ray": d["nodes_per_ray"], "triangles_per_ray": d["tris_per_ray"]},
             "kernel_ms": {name: stats.kernel_ms[i] for i, name in enumerate(hip_api.KERNEL_NAMES)},

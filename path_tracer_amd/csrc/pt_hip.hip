@@ -30,6 +30,9 @@
 static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device constants must agree");
 
 #define PT_BLOCK 256
+#ifndef PT_LIGHT_CACHE_SIZE
+#define PT_LIGHT_CACHE_SIZE 32 // lights whose importance a shading thread keeps in LDS (32 KB per workgroup)
+#endif
 #ifndef PT_SHADE_BLOCK
 #define PT_SHADE_BLOCK 256 // threads per workgroup of the shading kernel
 #endif
@@ -287,6 +290,13 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(PtShadeArgs a) {
 	uint32_t count = a.wf.ext_count[a.k - 1];
 	if (!pt_block_first_slot(count, &first_slot, PT_SHADE_BLOCK))
 		return;
+	// Per-light importances of this thread's vertex between the two loops of
+	// pt_sample_lights(): lane-contiguous, hence free of bank conflicts
+	__shared__ float light_importances[(STRATEGY == PT_STRATEGY_NEE) ? PT_LIGHT_CACHE_SIZE * PT_SHADE_BLOCK : 1];
+	PtLightCache light_cache;
+	light_cache.values = &light_importances[(STRATEGY == PT_STRATEGY_NEE) ? threadIdx.x : 0];
+	light_cache.stride = PT_SHADE_BLOCK;
+	light_cache.capacity = (STRATEGY == PT_STRATEGY_NEE) ? PT_LIGHT_CACHE_SIZE : 0;
 	uint32_t slot = first_slot + threadIdx.x;
 	bool active = slot < count;
 	uint32_t path = PT_INVALID;
@@ -306,7 +316,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(PtShadeArgs a) {
 		uint32_t sx = pt_as_uint(s0.w), sy = pt_as_uint(s1.w);
 		if (a.visit_counters && hit.x != PT_INVALID)
 			atomicAdd(&a.visit_counters[4], 1ull);
-		r = pt_shade_vertex(a.scene, *a.constants, STRATEGY, a.path_length, a.k,
+		r = pt_shade_vertex(a.scene, *a.constants, light_cache, STRATEGY, a.path_length, a.k,
 			hit.x, pt_as_float(hit.y), pt_as_float(hit.z), hit.w != 0, mk3(d.x, d.y, d.z),
 			radiance, throughput, nee_throughput, sx, sy);
 		a.wf.radiance[path] = mk4(radiance.x, radiance.y, radiance.z, 0.0f);

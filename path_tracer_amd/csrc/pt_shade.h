@@ -409,17 +409,30 @@ PT_FN v3 pt_sample_spherical_light(f32x4 light, float importance, v3 shading_pos
 	return pt_to_world(frame, mk3(r * ca, r * sa, z));
 }
 
+// Where pt_sample_lights() keeps the importances of its first loop for its
+// second one: entry i of a thread is at values[i * stride]. The reference
+// evaluates get_spherical_light_importance() anew in both loops; the values
+// are the same, so the result is too. Lights beyond capacity are recomputed.
+struct PtLightCache {
+	float* values;
+	uint32_t stride, capacity;
+};
+
 // ---- pathtrace.frag.glsl:120-143 ----
-PT_FN v3 pt_sample_lights(const PtSceneView& scene, float* out_total_importance, v3 shading_pos, v3 normal, v2 randoms) {
+PT_FN v3 pt_sample_lights(const PtSceneView& scene, const PtLightCache& cache, float* out_total_importance, v3 shading_pos, v3 normal, v2 randoms) {
 	float total = 0.0f;
-	for (uint32_t i = 0; i != scene.light_count; ++i)
-		total += pt_spherical_light_importance(scene.lights[i], shading_pos, normal);
+	for (uint32_t i = 0; i != scene.light_count; ++i) {
+		float importance = pt_spherical_light_importance(scene.lights[i], shading_pos, normal);
+		if (i < cache.capacity)
+			cache.values[i * cache.stride] = importance;
+		total += importance;
+	}
 	*out_total_importance = total;
 	float target_importance = randoms.x * total;
 	float prefix_importance = 0.0f;
 	for (uint32_t i = 0; i != scene.light_count; ++i) {
 		f32x4 light = scene.lights[i];
-		float importance = pt_spherical_light_importance(light, shading_pos, normal);
+		float importance = (i < cache.capacity) ? cache.values[i * cache.stride] : pt_spherical_light_importance(light, shading_pos, normal);
 		prefix_importance += importance;
 		if (prefix_importance > target_importance) {
 			randoms.x = ((target_importance + importance) - prefix_importance) / importance;
@@ -429,24 +442,28 @@ PT_FN v3 pt_sample_lights(const PtSceneView& scene, float* out_total_importance,
 	return mk3(0.0f, 0.0f, 0.0f);
 }
 
-// ---- pathtrace.frag.glsl:150-175 ----
-PT_FN float pt_lights_density(const PtSceneView& scene, float total_importance, v3 shading_pos, v3 sampled_dir, bool is_light_dir) {
+// ---- pathtrace.frag.glsl:150-175 for two directions at once: the first is
+// a direction towards a light (is_light_dir true), the second is not. One
+// pass over the lights serves both. ----
+PT_FN void pt_lights_density_2(const PtSceneView& scene, float total_importance, v3 shading_pos, v3 light_dir, v3 other_dir, float* out_light_dir_density, float* out_other_dir_density) {
+	*out_light_dir_density = *out_other_dir_density = 0.0f;
 	if (total_importance <= 0.0f)
-		return 0.0f;
-	float light_count = 0.0f;
+		return;
+	float count_0 = 0.0f, count_1 = 0.0f;
 	for (uint32_t i = 0; i != scene.light_count; ++i) {
 		f32x4 light = scene.lights[i];
 		v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
 		float center_dist_2 = dot(center_dir, center_dir);
-		float center_dot_dir = dot(center_dir, sampled_dir);
 		float radius_2 = light.w * light.w;
 		float in_sphere = center_dist_2 - radius_2;
-		float discriminant = center_dot_dir * center_dot_dir - in_sphere;
-		light_count += (discriminant >= 0.0f && in_sphere >= 0.0f && center_dot_dir >= 0.0f) ? 1.0f : 0.0f;
+		float center_dot_dir_0 = dot(center_dir, light_dir), center_dot_dir_1 = dot(center_dir, other_dir);
+		float discriminant_0 = center_dot_dir_0 * center_dot_dir_0 - in_sphere, discriminant_1 = center_dot_dir_1 * center_dot_dir_1 - in_sphere;
+		count_0 += (discriminant_0 >= 0.0f && in_sphere >= 0.0f && center_dot_dir_0 >= 0.0f) ? 1.0f : 0.0f;
+		count_1 += (discriminant_1 >= 0.0f && in_sphere >= 0.0f && center_dot_dir_1 >= 0.0f) ? 1.0f : 0.0f;
 	}
-	if (is_light_dir)
-		light_count = fmaxf(1.0f, light_count);
-	return light_count / (2.0f * PT_PI * total_importance);
+	count_0 = fmaxf(1.0f, count_0);
+	*out_light_dir_density = count_0 / (2.0f * PT_PI * total_importance);
+	*out_other_dir_density = count_1 / (2.0f * PT_PI * total_importance);
 }
 
 
@@ -464,7 +481,7 @@ struct PtVertexResult {
 // Shades vertex k (1-based) of a path. radiance, throughput, nee_throughput
 // and the seed are the path state and are updated in place. hit_prim ==
 // 0xffffffff means the extension ray left the scene.
-PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants& c, int strategy, uint32_t path_length, uint32_t k,
+PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants& c, const PtLightCache& light_cache, int strategy, uint32_t path_length, uint32_t k,
 	uint32_t hit_prim, float hit_u, float hit_v, bool hit_front, v3 ray_dir,
 	v3& radiance, v3& throughput, v3& nee_throughput, uint32_t& sx, uint32_t& sy)
 {
@@ -507,23 +524,26 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		r.continues = true;
 	}
 	else {
-		// pathtrace.frag.glsl:326-355
+		// pathtrace.frag.glsl:326-355. Both directions are sampled first (the
+		// light's random numbers are drawn before the BRDF's, as in the
+		// reference) so that one loop over the lights yields both densities.
 		float total_light_importance;
-		v3 light_dir = pt_sample_lights(scene, &total_light_importance, s.pos, s.normal, pt_random(sx, sy));
+		v3 light_dir = pt_sample_lights(scene, light_cache, &total_light_importance, s.pos, s.normal, pt_random(sx, sy));
 		float lambert_in_0 = dot(s.normal, light_dir);
+		r.next_dir = pt_sample_frostbite_brdf(s, pt_random(sx, sy));
+		float lambert_in_1 = dot(s.normal, r.next_dir);
+		float light_density_0 = 0.0f, light_density_1 = 0.0f;
+		if (lambert_in_0 > 0.0f || lambert_in_1 > 0.0f)
+			pt_lights_density_2(scene, total_light_importance, s.pos, light_dir, r.next_dir, &light_density_0, &light_density_1);
 		if (lambert_in_0 > 0.0f) {
-			float light_density_0 = pt_lights_density(scene, total_light_importance, s.pos, light_dir, true);
 			float brdf_density_0 = pt_frostbite_brdf_density(s, light_dir);
 			r.shadow = true;
 			r.shadow_dir = light_dir;
 			r.shadow_weight = throughput * pt_frostbite_brdf(s, light_dir);
 			r.shadow_factor = lambert_in_0 / (light_density_0 + brdf_density_0);
 		}
-		r.next_dir = pt_sample_frostbite_brdf(s, pt_random(sx, sy));
-		float lambert_in_1 = dot(s.normal, r.next_dir);
 		if (lambert_in_1 <= 0.0f)
 			return r;
-		float light_density_1 = pt_lights_density(scene, total_light_importance, s.pos, r.next_dir, false);
 		float brdf_density_1 = pt_frostbite_brdf_density(s, r.next_dir);
 		v3 brdf_lambert_1 = pt_frostbite_brdf(s, r.next_dir) * lambert_in_1;
 		nee_throughput = throughput * (brdf_lambert_1 / (light_density_1 + brdf_density_1));

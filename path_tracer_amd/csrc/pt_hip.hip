@@ -217,12 +217,15 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_extension(PtTraceArgs 
 	u32x4* hits = a.wf.hit;
 	pt_trace_wave<COUNT_VISITS>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
 		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters,
-		[&](uint32_t slot, float, float, const PtHit& hit) {
+		[&](uint32_t slot, float path_bits, float, const PtHit& hit) {
+			// Triangle indices stay below 2^31, so the front flag rides in the top
+			// bit (a miss is all ones); the path index comes along so that shading
+			// need not read the ray origin
 			u32x4 record;
-			record.x = hit.prim;
+			record.x = (hit.prim == PT_INVALID) ? PT_INVALID : (hit.prim | (hit.front ? 0x80000000u : 0u));
 			record.y = pt_as_uint(hit.u);
 			record.z = pt_as_uint(hit.v);
-			record.w = hit.front ? 1u : 0u;
+			record.w = pt_as_uint(path_bits);
 			hits[slot] = record;
 		});
 }
@@ -249,10 +252,16 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_shadow(PtTraceArgs a) 
 			else
 				emission = mk3(0.0f, 0.0f, 0.0f);
 			f32x4 w = a.wf.sh_w[slot];
-			uint32_t path = pt_as_uint(path_bits);
-			f32x4 radiance = a.wf.radiance[path];
-			v3 sum = mk3(radiance.x, radiance.y, radiance.z) + (mk3(w.x, w.y, w.z) * emission) * factor;
-			a.wf.radiance[path] = mk4(sum.x, sum.y, sum.z, 0.0f);
+			v3 term = (mk3(w.x, w.y, w.z) * emission) * factor;
+			// Adding a zero leaves the radiance as it is (it is never -0), so the
+			// read-modify-write happens only for terms that are not zero; a NaN
+			// from an infinite weight compares unequal and is added as well
+			if (term.x != 0.0f || term.y != 0.0f || term.z != 0.0f) {
+				uint32_t path = pt_as_uint(path_bits);
+				f32x4 radiance = a.wf.radiance[path];
+				v3 sum = mk3(radiance.x, radiance.y, radiance.z) + term;
+				a.wf.radiance[path] = mk4(sum.x, sum.y, sum.z, 0.0f);
+			}
 		});
 }
 
@@ -303,23 +312,29 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(PtShadeArgs a) {
 	PtVertexResult r;
 	r.continues = false;
 	r.shadow = false;
+	u32x4 hit;
 	if (active) {
-		f32x4 o = a.wf.ray_o[a.parity][slot];
-		path = pt_as_uint(o.w);
+		hit = a.wf.hit[slot];
+		path = hit.w;
 		active = path != PT_INVALID;
 	}
 	if (active) {
 		f32x4 d = a.wf.ray_d[a.parity][slot];
-		u32x4 hit = a.wf.hit[slot];
-		f32x4 s0 = a.wf.state0[path], s1 = a.wf.state1[path], rad = a.wf.radiance[path];
-		v3 throughput = mk3(s0.x, s0.y, s0.z), nee_throughput = mk3(s1.x, s1.y, s1.z), radiance = mk3(rad.x, rad.y, rad.z);
+		f32x4 s0 = a.wf.state0[path], s1 = a.wf.state1[path];
+		v3 throughput = mk3(s0.x, s0.y, s0.z), nee_throughput = mk3(s1.x, s1.y, s1.z), emitted = mk3(0.0f, 0.0f, 0.0f);
 		uint32_t sx = pt_as_uint(s0.w), sy = pt_as_uint(s1.w);
-		if (a.visit_counters && hit.x != PT_INVALID)
+		bool missed = hit.x == PT_INVALID;
+		if (a.visit_counters && !missed)
 			atomicAdd(&a.visit_counters[4], 1ull);
 		r = pt_shade_vertex(a.scene, *a.constants, light_cache, STRATEGY, a.path_length, a.k,
-			hit.x, pt_as_float(hit.y), pt_as_float(hit.z), hit.w != 0, mk3(d.x, d.y, d.z),
-			radiance, throughput, nee_throughput, sx, sy);
-		a.wf.radiance[path] = mk4(radiance.x, radiance.y, radiance.z, 0.0f);
+			missed ? PT_INVALID : (hit.x & 0x7fffffffu), pt_as_float(hit.y), pt_as_float(hit.z), (hit.x >> 31) != 0, mk3(d.x, d.y, d.z),
+			emitted, throughput, nee_throughput, sx, sy);
+		// Emission is zero at most vertices; radiance + 0 is the radiance (it is
+		// never -0), so only other terms, NaN included, touch the path's radiance
+		if (emitted.x != 0.0f || emitted.y != 0.0f || emitted.z != 0.0f) {
+			f32x4 rad = a.wf.radiance[path];
+			a.wf.radiance[path] = mk4(rad.x + emitted.x, rad.y + emitted.y, rad.z + emitted.z, 0.0f);
+		}
 		if (r.continues) {
 			a.wf.state0[path] = mk4(throughput.x, throughput.y, throughput.z, pt_as_float(sx));
 			a.wf.state1[path] = mk4(nee_throughput.x, nee_throughput.y, nee_throughput.z, pt_as_float(sy));
@@ -373,10 +388,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_gather_primary_hits(PtBatch batch,
 		return;
 	uint64_t pixel = (uint64_t) y * batch.width + x;
 	u32x4 hit = wf.hit[p];
-	triangles[pixel] = (int32_t) hit.x;
+	triangles[pixel] = (hit.x == PT_INVALID) ? -1 : (int32_t) (hit.x & 0x7fffffffu);
 	barycentrics[2 * pixel] = pt_as_float(hit.y);
 	barycentrics[2 * pixel + 1] = pt_as_float(hit.z);
-	front[pixel] = (uint8_t) hit.w;
+	front[pixel] = (uint8_t) ((hit.x != PT_INVALID) ? (hit.x >> 31) : 0u);
 }
 
 struct PtUserRayArgs {

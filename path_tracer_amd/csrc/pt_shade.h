@@ -478,12 +478,14 @@ struct PtVertexResult {
 	float shadow_factor; // lambert / (light density + brdf density)
 };
 
-// Shades vertex k (1-based) of a path. radiance, throughput, nee_throughput
-// and the seed are the path state and are updated in place. hit_prim ==
-// 0xffffffff means the extension ray left the scene.
+// Shades vertex k (1-based) of a path. throughput, nee_throughput and the
+// seed are the path state and are updated in place; emitted receives what
+// the caller has to add to the path's radiance (the weighted emission of the
+// surface or the sky). hit_prim == 0xffffffff means the extension ray left
+// the scene.
 PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants& c, const PtLightCache& light_cache, int strategy, uint32_t path_length, uint32_t k,
 	uint32_t hit_prim, float hit_u, float hit_v, bool hit_front, v3 ray_dir,
-	v3& radiance, v3& throughput, v3& nee_throughput, uint32_t& sx, uint32_t& sy)
+	v3& emitted, v3& throughput, v3& nee_throughput, uint32_t& sx, uint32_t& sy)
 {
 	PtVertexResult r;
 	r.continues = false;
@@ -494,11 +496,11 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 	// others by throughput (pathtrace.frag.glsl:231,265,293,323)
 	v3 emission_weight = (strategy == PT_STRATEGY_NEE) ? nee_throughput : throughput;
 	if (hit_prim == 0xffffffffu) {
-		radiance = radiance + emission_weight * mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
+		emitted = emission_weight * mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
 		return r;
 	}
 	PtShadingData s = pt_shading_data(scene, c, hit_prim, hit_u, hit_v, hit_front, -ray_dir);
-	radiance = radiance + emission_weight * s.emission;
+	emitted = emission_weight * s.emission;
 	if (k >= path_length)
 		return r;
 	r.next_origin = s.pos;

@@ -335,7 +335,9 @@ uint64_t emu_render(EmuScene* s, const PtConstants* c, int strategy, uint32_t pa
 				// A cache smaller than some tests' light counts exercises both of its branches
 				float cached_importances[8];
 				PtLightCache light_cache = { cached_importances, 1, 8 };
-				PtVertexResult r = pt_shade_vertex(scene, *c, light_cache, strategy, path_length, k, hit.prim, hit.u, hit.v, hit.front, d, radiance, throughput, nee, sx, sy);
+				v3 emitted;
+				PtVertexResult r = pt_shade_vertex(scene, *c, light_cache, strategy, path_length, k, hit.prim, hit.u, hit.v, hit.front, d, emitted, throughput, nee, sx, sy);
+				radiance = radiance + emitted;
 				if (r.shadow) {
 					EmuStack sstack;
 					PtHit sh = pt_trace_closest<false>(scene.nodes, scene.tris, s->n, r.next_origin, r.shadow_dir, 1.0e-3f, 1e38f, sstack, NULL);

@@ -84,17 +84,38 @@ __global__ void __launch_bounds__(PT_BLOCK) k_build_radix_tree(PtBuild b) {
 		pt_build_radix_tree(b, i);
 }
 
+// Arrival at an inner node during a bottom-up pass: the counter orders this
+// thread's stores before it and its later loads after it at device scope
+__device__ __forceinline__ uint32_t pt_build_arrive(uint32_t* flag) {
+	__threadfence();
+	uint32_t old = atomicAdd(flag, 1u);
+	__threadfence();
+	return old;
+}
+
 __global__ void __launch_bounds__(PT_BLOCK) k_build_refit(PtBuild b) {
 	uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
 	if (k >= b.n)
 		return;
 	PtSceneBounds sb = pt_build_get_bounds(b.bounds);
-	pt_build_refit(b, sb.pad, k, [](uint32_t* flag) {
-		__threadfence();
-		uint32_t old = atomicAdd(flag, 1u);
-		__threadfence();
-		return old;
-	});
+	pt_build_refit(b, sb.pad, k, [](uint32_t* flag) { return pt_build_arrive(flag); });
+}
+
+// One pass of treelet restructuring over the whole binary tree
+__global__ void __launch_bounds__(PT_BLOCK) k_build_treelets(PtBuild b) {
+	uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (k >= b.n)
+		return;
+	PtTreeletScratch scratch;
+	pt_build_climb(b, k, pt_build_arrive, [&](uint32_t node) { pt_build_treelet(b, node, scratch); });
+}
+
+// Costs and choices of the wide collapse, bottom-up over the final binary tree
+__global__ void __launch_bounds__(PT_BLOCK) k_build_wide_costs(PtBuild b) {
+	uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (k >= b.n)
+		return;
+	pt_build_climb(b, k, pt_build_arrive, [&](uint32_t node) { pt_build_wide_cost(b, node); });
 }
 
 __global__ void __launch_bounds__(PT_BLOCK) k_build_collapse(PtBuild b, uint32_t level_begin, uint32_t level_end) {
@@ -677,7 +698,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 		if (pt_alloc(&b.verts, 9 * (uint64_t) n) || pt_alloc(&b.bounds, 6) || pt_alloc(&b.keys, n) || pt_alloc(&b.order, n)
 			|| pt_alloc(&keys_sorted, n) || pt_alloc(&order_sorted, n)
 			|| pt_alloc(&b.left, n) || pt_alloc(&b.right, n) || pt_alloc(&b.parent, 2 * (uint64_t) n)
-			|| pt_alloc(&b.wide_cost, 8 * (uint64_t) n) || pt_alloc(&b.wide_choice, 8 * (uint64_t) n) || pt_alloc(&b.box, 12 * (uint64_t) n)
+			|| pt_alloc(&b.size, n) || pt_alloc(&b.sah_cost, n) || pt_alloc(&b.wide_cost, 8 * (uint64_t) n) || pt_alloc(&b.wide_choice, 8 * (uint64_t) n) || pt_alloc(&b.box, 12 * (uint64_t) n)
 			|| pt_alloc(&b.flags, n) || pt_alloc(&b.task_binary, max_nodes) || pt_alloc(&b.counters, 2))
 			break;
 		b.nodes = s->nodes;
@@ -704,6 +725,15 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 		if (n > 1)
 			hipLaunchKernelGGL(k_build_radix_tree, dim3(pt_grid(n - 1)), dim3(PT_BLOCK), 0, s->stream, b);
 		hipLaunchKernelGGL(k_build_refit, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+		// Treelet restructuring passes, then the costs of the wide collapse
+		for (int pass = 0; pass <= PT_TREELET_PASSES && n > 1; ++pass) {
+			if (hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * n, s->stream) != hipSuccess)
+				break;
+			if (pass < PT_TREELET_PASSES)
+				hipLaunchKernelGGL(k_build_treelets, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+			else
+				hipLaunchKernelGGL(k_build_wide_costs, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+		}
 		// Collapse level by level: the nodes allocated while processing one
 		// level form the next level
 		uint32_t level_begin = 0, level_end = 1, depth = 0;
@@ -737,7 +767,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 	hipEventDestroy(begin);
 	hipEventDestroy(end);
 	hipFree(b.verts); hipFree(b.bounds); hipFree(b.keys); hipFree(b.order); hipFree(keys_sorted); hipFree(order_sorted);
-	hipFree(b.left); hipFree(b.right); hipFree(b.parent); hipFree(b.wide_cost); hipFree(b.wide_choice); hipFree(b.box);
+	hipFree(b.left); hipFree(b.right); hipFree(b.parent); hipFree(b.size); hipFree(b.sah_cost); hipFree(b.wide_cost); hipFree(b.wide_choice); hipFree(b.box);
 	hipFree(b.flags); hipFree(b.task_binary); hipFree(b.counters); hipFree(sort_temp);
 	s->bvh_info.node_bytes = sizeof(PtNode);
 	s->bvh_info.triangle_bytes = sizeof(PtTri);

@@ -231,6 +231,21 @@ EmuScene* emu_create_scene(uint64_t material_count, uint64_t triangle_count, con
 	for (uint32_t i = 0; i + 1 < n; ++i) pt_build_radix_tree(b, i);
 	for (uint32_t i = 0; i != n; ++i)
 		pt_build_refit(b, sb.pad, i, [](uint32_t* flag) { return (*flag)++; });
+	// Treelet passes and the wide-collapse costs, as in pt_build_bvh()
+	std::vector<uint32_t> size(n);
+	std::vector<float> sah_cost(n);
+	b.size = size.data(); b.sah_cost = sah_cost.data();
+	const char* passes_text = getenv("PT_EMU_TREELET_PASSES");
+	int passes = passes_text ? atoi(passes_text) : PT_TREELET_PASSES;
+	for (int pass = 0; pass != passes; ++pass) {
+		std::fill(flags.begin(), flags.end(), 0u);
+		PtTreeletScratch scratch;
+		for (uint32_t i = 0; i != n; ++i)
+			pt_build_climb(b, i, [](uint32_t* flag) { return (*flag)++; }, [&](uint32_t node) { pt_build_treelet(b, node, scratch); });
+	}
+	std::fill(flags.begin(), flags.end(), 0u);
+	for (uint32_t i = 0; i != n; ++i)
+		pt_build_climb(b, i, [](uint32_t* flag) { return (*flag)++; }, [&](uint32_t node) { pt_build_wide_cost(b, node); });
 	const char* builder = getenv("PT_EMU_BUILDER");
 	uint32_t root = 0;
 	if (builder && !strcmp(builder, "sah") && n > 1) {

@@ -134,3 +134,31 @@ def test_duplicate_triangles_tie_break():
     a, b = o_scene.trace_rays(o, d), e_scene.trace_rays(o, d)
     assert (a[0] == b[0]).all()
     assert (a[0][a[0] >= 0] < 200).all()
+
+
+def test_tree_quality_against_sah_yardstick(tmp_path, monkeypatch):
+    """The builder's tree (radix tree + optimal wide collapse) against a top-down binned-SAH tree over the same
+    collapse: same hits, and at most 1.15 times the node visits per ray on a generated scene (without the treelet
+    passes the radix tree needs 1.44 times)."""
+    from oracle import formats
+    from path_tracer_amd.tools import procedural
+    root = str(tmp_path / "hall")
+    procedural.ensure_scene("interior", root, triangles=40000, texture_size=16, material_count=8)
+    scene = formats.load_scene(root + "/data/Arcade.vks", root + "/data/Arcade_textures")
+    rng = np.random.default_rng(4)
+    o = rng.uniform([0.5, 0.5, 0.2], [23.5, 15.5, 4.5], (20000, 3)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    results = {}
+    for builder in ("lbvh", "sah"):
+        monkeypatch.setenv("PT_EMU_BUILDER", builder)
+        tree = emu.EmuScene(scene)
+        tri, tuv, front, visits = tree.trace_rays(o, d)
+        results[builder] = (tri, bits(tuv), visits[0] / len(o), visits[1] / len(o), tree.bvh_info())
+        tree.close()
+    assert (results["lbvh"][0] == results["sah"][0]).all() and (results["lbvh"][1] == results["sah"][1]).all()
+    assert (results["lbvh"][0] >= 0).mean() > 0.99  # a closed hall
+    print("nodes per ray: builder %.2f, yardstick %.2f" % (results["lbvh"][2], results["sah"][2]))
+    assert results["lbvh"][2] <= 1.15 * results["sah"][2], (results["lbvh"][2], results["sah"][2])
+    assert results["lbvh"][3] <= 8.0  # one triangle per leaf child: few triangle tests per ray
+    assert results["lbvh"][4]["node_count"] < scene.triangle_count / 3

@@ -157,6 +157,22 @@ static_assert(sizeof(PtTri) == 48, "triangle layout");
 // One material texture; mip payloads are raw BC1/BC5 blocks in one device
 // blob (format: VkFormat number 131 BC1_RGB_UNORM, 132 BC1_RGB_SRGB, 141
 // BC5_UNORM, as in the .vkt header read by src/textures.c:71-84)
+// x / 255 and x / 65535 for the integers that 8- and 16-bit unorm texels
+// hold, bit-identical to the IEEE quotient for every such x (checked
+// exhaustively by the tests): a product with the rounded reciprocal, corrected
+// once through its exact residual. Three instructions on the GPU where the
+// correctly rounded division takes ten.
+PT_FN float pt_unorm8(uint32_t x) {
+	const float r = 1.0f / 255.0f;
+	float f = (float) x, q = f * r;
+	return fmaf(fmaf(-q, 255.0f, f), r, q);
+}
+PT_FN float pt_unorm16(uint32_t x) {
+	const float r = 1.0f / 65535.0f;
+	float f = (float) x, q = f * r;
+	return fmaf(fmaf(-q, 65535.0f, f), r, q);
+}
+
 struct PtTexture {
 	uint32_t width, height, format, mip_count;
 	uint64_t mip_offsets[PT_MAX_MIPS];

@@ -186,14 +186,14 @@ PT_FN v3 pt_fetch_texel(const PtSceneView& s, u32x2 t, int32_t x, int32_t y) {
 		u32x4 w = *(const u32x4*) (mip_0 + block * 16);
 		uint32_t r = pt_decode_bc4(w.x, w.y, ux & 3, uy & 3);
 		uint32_t g = pt_decode_bc4(w.z, w.w, ux & 3, uy & 3);
-		return mk3((float) r / 255.0f, (float) g / 255.0f, 0.0f);
+		return mk3(pt_unorm8(r), pt_unorm8(g), 0.0f);
 	}
 	u32x2 w = *(const u32x2*) (mip_0 + block * 8);
 	uint32_t r, g, b;
 	pt_decode_bc1(w.x, w.y, ux & 3, uy & 3, &r, &g, &b);
 	if (format == 132)
 		return mk3(s.srgb_to_linear[r], s.srgb_to_linear[g], s.srgb_to_linear[b]);
-	return mk3((float) r / 255.0f, (float) g / 255.0f, (float) b / 255.0f);
+	return mk3(pt_unorm8(r), pt_unorm8(g), pt_unorm8(b));
 }
 
 PT_FN v3 pt_sample_texture(const PtSceneView& s, uint32_t texture_index, v2 uv) {
@@ -235,8 +235,8 @@ PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants&
 	for (int i = 0; i != 3; ++i) {
 		u32x2 qp = vertex_positions[i];
 		u32x2 qn = vertex_normals_uvs[i];
-		float n0 = (float) (qn.x & 0xffffu) / 65535.0f, n1 = (float) (qn.x >> 16) / 65535.0f;
-		float t0 = (float) (qn.y & 0xffffu) / 65535.0f, t1 = (float) (qn.y >> 16) / 65535.0f;
+		float n0 = pt_unorm16(qn.x & 0xffffu), n1 = pt_unorm16(qn.x >> 16);
+		float t0 = pt_unorm16(qn.y & 0xffffu), t1 = pt_unorm16(qn.y >> 16);
 		poss[i] = pt_dequantize_position(qp, c.dequantization_factor, c.dequantization_summand);
 		s.pos = s.pos + poss[i] * barys[i];
 		normal_geo = normal_geo + pt_dequantize_normal(n0, n1) * barys[i];

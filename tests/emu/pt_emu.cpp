@@ -296,6 +296,14 @@ void emu_set_lights(EmuScene* s, const float* lights, uint32_t count) {
 void emu_bvh_info(EmuScene* s, uint32_t* out) { out[0] = s->node_count; out[1] = s->depth; out[2] = s->max_stack; }
 double emu_binary_tree_cost(EmuScene* s) { return s->binary_cost; }
 
+// Number of integers x for which the reciprocal-based unorm conversions differ from the IEEE quotient
+uint32_t emu_unorm_mismatches() {
+	uint32_t mismatches = 0;
+	for (uint32_t x = 0; x != 256; ++x) mismatches += pt_as_uint(pt_unorm8(x)) != pt_as_uint((float) x / 255.0f);
+	for (uint32_t x = 0; x != 65536; ++x) mismatches += pt_as_uint(pt_unorm16(x)) != pt_as_uint((float) x / 65535.0f);
+	return mismatches;
+}
+
 void emu_trace_rays(EmuScene* s, const float* origins, const float* directions, uint32_t count, int32_t* triangles, float* tuv, uint8_t* front, uint64_t* visits_out) {
 	uint64_t total[2] = { 0, 0 };
 	for (uint32_t i = 0; i != count; ++i) {

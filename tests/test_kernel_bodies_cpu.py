@@ -41,6 +41,11 @@ def test_elementary_functions_bitwise():
         assert a == b or (np.isnan(a) and np.isnan(b))
 
 
+def test_unorm_conversions_equal_ieee_division():
+    """x / 255 and x / 65535 by reciprocal and one residual correction: the same bits as the division for every texel value."""
+    assert emu.lib().emu_unorm_mismatches() == 0
+
+
 def test_bvh_shape_cornell(emu_cornell):
     info = emu_cornell.bvh_info()
     assert 1310 / 24 <= info["node_count"] <= 1310

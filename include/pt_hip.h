@@ -103,8 +103,10 @@ int pt_set_lights(pt_scene_t* scene, const float* lights, uint32_t count);
 int pt_set_render_settings(pt_scene_t* scene, int sampling_strategy, uint32_t path_length, uint32_t emission_material_index);
 
 /* create_render_targets() at src/main.c:519-560: allocates the RGBA32F
- * accumulation target and the wavefront buffers for this resolution and
- * resets the accumulated sample count. */
+ * accumulation target for this resolution and resets the accumulated sample
+ * count. The ray queues and path states (176 bytes per path) are allocated by
+ * the first pt_render_samples() call for as many frames as it renders at
+ * once: up to 64 M paths, 11.8 GB, when many samples are requested. */
 int pt_create_render_targets(pt_scene_t* scene, uint32_t width, uint32_t height);
 
 /* Renders sample_count frames; sample s uses g_frame_index =
@@ -156,7 +158,9 @@ int pt_set_instrumentation(pt_scene_t* scene, int enable_kernel_timing, int enab
 int pt_get_statistics(pt_scene_t* scene, pt_statistics_t* out_statistics);
 int pt_reset_statistics(pt_scene_t* scene);
 
-/* Facts about the BVH that was built (sizes of its arrays in HBM). */
+/* Facts about the BVH that was built: numbers of 8-wide nodes and of
+ * triangles in its arrays in HBM, levels, bytes per node and per triangle,
+ * and the time the build took on the GPU. */
 typedef struct {
 	uint32_t node_count;
 	uint32_t triangle_count;

@@ -145,21 +145,6 @@ __device__ __forceinline__ bool pt_block_first_slot(uint32_t count, uint32_t* ou
 	return true;
 }
 
-// Reserves one queue slot for every lane with want set: one atomic per wave
-__device__ __forceinline__ uint32_t pt_wave_push(uint32_t* counter, bool want) {
-	unsigned long long mask = __ballot(want);
-	uint32_t total = (uint32_t) __popcll(mask);
-	uint32_t prefix = __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
-	uint32_t base = 0;
-	if (total) {
-		uint32_t leader = (uint32_t) __builtin_ctzll(mask);
-		if ((threadIdx.x & 63) == leader)
-			base = atomicAdd(counter, total);
-		base = (uint32_t) __shfl((int) base, (int) leader);
-	}
-	return base + prefix;
-}
-
 // Reserves slots in two queues for the lanes of a whole workgroup with two
 // atomics per workgroup. Counters that every wave of a launch adds to are
 // served one after the other by a single L2 channel, a few nanoseconds each:

@@ -308,3 +308,28 @@ def test_display_image_and_jpg(tmp_path):
     error = np.sqrt(((np.asarray(Image.open(jpg)).astype(float) - srgb) ** 2).mean())
     assert error < 1.25 * np.sqrt(((np.asarray(Image.open(other)).astype(float) - srgb) ** 2).mean()) + 0.5
     renderer.close()
+
+
+def test_full_size_results_do_not_depend_on_batching(monkeypatch):
+    """1920x1080, 24 spp: one call with all frames in one wavefront batch, two calls (5 + 19 frames), and batches of two
+    frames give the same bits, because every pixel adds its frames in frame order whatever the batch layout."""
+    spec = host_api.quickload(os.path.join(DATA, "saves", "cornell_box", "default.rt_save"))
+    images, rays = [], []
+    for batch_paths, calls in ((None, (24,)), (None, (5, 19)), ("3000000", (24,))):
+        if batch_paths is None:
+            monkeypatch.delenv("PT_BATCH_PATHS", raising=False)
+        else:
+            monkeypatch.setenv("PT_BATCH_PATHS", batch_paths)
+        renderer = host_api.Renderer(spec, DATA_ROOT, device=0, width=1920, height=1080)
+        for count in calls:
+            renderer.render_frames(count)
+        image, samples = renderer.read_accumulation()
+        stats = renderer.statistics()
+        assert samples == 24 and renderer.spec.frame_index == spec.frame_index + 24
+        images.append(image)
+        rays.append(stats.extension_rays + stats.shadow_rays)
+        renderer.close()
+    assert (bits(images[0]) == bits(images[1])).all() and (bits(images[0]) == bits(images[2])).all()
+    assert rays[0] == rays[1] == rays[2] and rays[0] > 2.5 * 24 * 1920 * 1080
+    mean = images[0][..., :3].mean() / 24
+    assert np.isfinite(images[0]).all() and 0.2 < mean < 2.0 and (images[0][..., 3] == 1.0).all()

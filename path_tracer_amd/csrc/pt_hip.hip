@@ -529,6 +529,16 @@ static uint32_t pt_grid_chunked(uint64_t capacity, uint32_t block_size = PT_BLOC
 	return chunk ? 8 * chunk : 8;
 }
 
+// Workgroups for a traversal launch over at most ray_count rays. A launch
+// ends when its last wave has finished its last ray, so a short queue (one
+// 1080p frame is 2 M rays, four per lane of the full grid) is done sooner by
+// one workgroup per CU than by two: measured 4.0 instead of 3.5 Grays/s.
+static uint32_t pt_trace_grid(const pt_scene* s, uint64_t ray_count) {
+	if (ray_count < (4ull << 20))
+		return s->trace_grid / PT_TRACE_BLOCKS_PER_CU;
+	return s->trace_grid;
+}
+
 static PtSceneView pt_scene_view(const pt_scene* s) {
 	PtSceneView v;
 	v.nodes = s->nodes;
@@ -1013,9 +1023,9 @@ static void pt_launch_trace_extension(pt_scene* s, uint32_t bounce, uint32_t par
 	pt_launch_timer timer(s, PT_K_TRACE_EXT);
 	PtTraceArgs a = pt_trace_args(s, bounce, parity, false);
 	if (s->visit_counters_enabled)
-		hipLaunchKernelGGL(k_trace_extension<true>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+		hipLaunchKernelGGL(k_trace_extension<true>, dim3(pt_trace_grid(s, capacity)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 	else
-		hipLaunchKernelGGL(k_trace_extension<false>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+		hipLaunchKernelGGL(k_trace_extension<false>, dim3(pt_trace_grid(s, capacity)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 }
 
 // Renders one batch of frame_count frames
@@ -1057,9 +1067,9 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 			pt_launch_timer timer(s, PT_K_TRACE_SHADOW);
 			PtTraceArgs a = pt_trace_args(s, k, 0, true);
 			if (s->visit_counters_enabled)
-				hipLaunchKernelGGL(k_trace_shadow<true>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+				hipLaunchKernelGGL(k_trace_shadow<true>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 			else
-				hipLaunchKernelGGL(k_trace_shadow<false>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+				hipLaunchKernelGGL(k_trace_shadow<false>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 		}
 		parity ^= 1;
 	}
@@ -1234,7 +1244,7 @@ extern "C" int pt_trace_primary_rays(pt_scene_t* s, const pt_constants_t* consta
 			break;
 		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count, path_count);
 		PtTraceArgs a = pt_trace_args(s, 0, 0, false);
-		hipLaunchKernelGGL(k_trace_extension<false>, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+		hipLaunchKernelGGL(k_trace_extension<false>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 		hipLaunchKernelGGL(k_gather_primary_hits, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->wf, d_triangles, d_barycentrics, d_front);
 		if (hipMemcpyAsync(triangle_indices, d_triangles, pixels * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess
 			|| hipMemcpyAsync(barycentrics, d_barycentrics, 2 * pixels * sizeof(float), hipMemcpyDeviceToHost, s->stream) != hipSuccess
@@ -1290,7 +1300,7 @@ extern "C" int pt_trace_rays(pt_scene_t* s, const float* origins, const float* d
 		a.triangles = d_triangles;
 		a.t_u_v = d_tuv;
 		a.front = d_front;
-		hipLaunchKernelGGL(k_trace_user_rays, dim3(s->trace_grid), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+		hipLaunchKernelGGL(k_trace_user_rays, dim3(pt_trace_grid(s, ray_count)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 		if (hipMemcpyAsync(triangle_indices, d_triangles, sizeof(int32_t) * ray_count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
 			|| hipMemcpyAsync(t_u_v, d_tuv, sizeof(float) * 3 * ray_count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
 			|| hipMemcpyAsync(front, d_front, ray_count, hipMemcpyDeviceToHost, s->stream) != hipSuccess

@@ -44,7 +44,10 @@
 #define PT_REFILL_MIN 16     // idle lanes that trigger a refill
 #endif
 #ifndef PT_RESERVE
-#define PT_RESERVE 256       // rays a wave reserves from the queue per atomic
+#define PT_RESERVE 256       // rays a wave reserves from the queue per atomic, at most
+#endif
+#ifndef PT_RESERVE_MIN
+#define PT_RESERVE_MIN 64    // and at least: short queues are handed out in smaller portions
 #endif
 #ifndef PT_FETCH_STRIDE
 #define PT_FETCH_STRIDE 32   // words between the fetch counters of the eighths (one 128-byte line each)
@@ -125,7 +128,13 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	const uint32_t lane = pt_lane();
 	const uint32_t ray_total = *queue.count;
 	// Eighths of the queue, in multiples of the reservation size
-	const uint32_t chunk_len = ((ray_total + 8 * PT_RESERVE - 1) / (8 * PT_RESERVE)) * PT_RESERVE;
+	// A wave reserves rays in portions: large ones keep the atomics rare,
+	// but a queue that is short for the number of waves must be split finely
+	// enough for the waves to share it evenly (about eight portions per wave)
+	uint32_t reserve = PT_RESERVE;
+	while (reserve > PT_RESERVE_MIN && (uint64_t) reserve * gridDim.x * PT_WAVES_PER_BLOCK * 8u > ray_total)
+		reserve >>= 1;
+	const uint32_t chunk_len = ((ray_total + 8 * reserve - 1) / (8 * reserve)) * reserve;
 	uint32_t chunk = blockIdx.x & 7, chunks_tried = 0;
 	// Rays reserved by this wave and not yet handed to a lane (wave-uniform)
 	uint32_t reserve_next = 0, reserve_end = 0;
@@ -177,12 +186,12 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				uint32_t base = chunk_len;
 				if (chunk_begin < chunk_end) {
 					if (lane == 0)
-						base = atomicAdd(&queue.fetch[chunk * PT_FETCH_STRIDE], (uint32_t) PT_RESERVE);
+						base = atomicAdd(&queue.fetch[chunk * PT_FETCH_STRIDE], reserve);
 					base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
 				}
 				if (chunk_begin + base < chunk_end) {
 					reserve_next = chunk_begin + base;
-					reserve_end = reserve_next + PT_RESERVE;
+					reserve_end = reserve_next + reserve;
 					if (reserve_end > chunk_end) reserve_end = chunk_end;
 				}
 				else {

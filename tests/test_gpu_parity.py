@@ -333,3 +333,22 @@ def test_full_size_results_do_not_depend_on_batching(monkeypatch):
     assert rays[0] == rays[1] == rays[2] and rays[0] > 2.5 * 24 * 1920 * 1080
     mean = images[0][..., :3].mean() / 24
     assert np.isfinite(images[0]).all() and 0.2 < mean < 2.0 and (images[0][..., 3] == 1.0).all()
+
+
+def test_convergence_against_higher_sample_count_oracle(gpu_cornell, oracle_cornell, cornell, cornell_lights, cornell_spec):
+    """Relative RMSE of the mean radiance against a 16 times higher-spp oracle image made of other frames: it falls like
+    1 / sqrt(spp) (Monte Carlo, independent frames), so 64 spp is about twice as close as 16 spp."""
+    width = height = 64
+    constants = oracle.write_constants(cornell_spec, width, height, cornell, cornell_lights)
+    reference, _ = oracle_cornell.render(constants, cornell_lights, first_frame_index=100000, frame_count=1024, threads=16)
+    reference = reference[..., :3] / 1024.0
+    gpu_cornell.create_render_targets(width, height)
+    gpu_cornell.set_render_settings(hip_api.SAMPLING_STRATEGY_NEE, 4, cornell.emission_material_index)
+    errors = {}
+    for spp in (16, 64):
+        gpu_cornell.render_samples(to_gpu_constants(constants), 2696, spp, accumulate=False)
+        image, count = gpu_cornell.read_accumulation()
+        mean = image[..., :3] / count
+        errors[spp] = float(np.sqrt(((mean - reference) ** 2).mean()) / reference.mean())
+    assert errors[64] < 0.3, errors  # a small light: 0.21 measured, the oracle image itself has about 0.05
+    assert 1.5 < errors[16] / errors[64] < 2.6, errors

@@ -92,7 +92,8 @@ def cpu_baseline(args, threads, root, first_frame_index):
     scene = formats.load_scene(os.path.join(data, name + ".vks"), os.path.join(data, textures))
     lights = formats.load_lights(os.path.join(data, name + ".lights"))
     spec = formats.load_rt_save(os.path.join(data, "saves", save))
-    width, height, spp = args.width // 2, args.height // 2, (16 if args.workload == "cornell" else 4)
+    # About 10-30 s of CPU work: one step of the Cornell workload, a quarter of one for the larger scenes
+    width, height, spp = args.width, args.height, (32 if args.workload == "cornell" else 8)
     constants = oracle.write_constants(spec, width, height, scene, lights)
     cpu_scene = oracle.OracleScene(scene)
     begin = time.perf_counter()

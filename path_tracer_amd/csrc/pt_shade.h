@@ -499,10 +499,17 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		emitted = emission_weight * mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
 		return r;
 	}
+	if (k >= path_length) {
+		// The last vertex of a path contributes its emission only
+		// (pathtrace.frag.glsl:323-325 and the loop bound), and the emission
+		// depends on nothing but the material (shading_data.glsl:100-101)
+		bool emissive = scene.shade_tris[hit_prim].material == scene.emission_material_index;
+		v3 emission = emissive ? mk3(c.emission_material_radiance[0], c.emission_material_radiance[1], c.emission_material_radiance[2]) : mk3(0.0f, 0.0f, 0.0f);
+		emitted = emission_weight * emission;
+		return r;
+	}
 	PtShadingData s = pt_shading_data(scene, c, hit_prim, hit_u, hit_v, hit_front, -ray_dir);
 	emitted = emission_weight * s.emission;
-	if (k >= path_length)
-		return r;
 	r.next_origin = s.pos;
 	if (strategy == PT_STRATEGY_SPHERICAL || strategy == PT_STRATEGY_PSA) {
 		// pathtrace.frag.glsl:234-240 and :268-274

@@ -721,14 +721,18 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 			hipLaunchKernelGGL(k_build_radix_tree, dim3(pt_grid(n - 1)), dim3(PT_BLOCK), 0, s->stream, b);
 		hipLaunchKernelGGL(k_build_refit, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
 		// Treelet restructuring passes, then the costs of the wide collapse
-		for (int pass = 0; pass <= PT_TREELET_PASSES && n > 1; ++pass) {
-			if (hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * n, s->stream) != hipSuccess)
+		bool passes_failed = false;
+		for (int pass = 0; pass <= PT_TREELET_PASSES && n > 1 && !passes_failed; ++pass) {
+			passes_failed = hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * n, s->stream) != hipSuccess;
+			if (passes_failed)
 				break;
 			if (pass < PT_TREELET_PASSES)
 				hipLaunchKernelGGL(k_build_treelets, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
 			else
 				hipLaunchKernelGGL(k_build_wide_costs, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
 		}
+		if (passes_failed)
+			break;
 		// Collapse level by level: the nodes allocated while processing one
 		// level form the next level
 		uint32_t level_begin = 0, level_end = 1, depth = 0;

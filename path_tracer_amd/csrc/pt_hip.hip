@@ -512,6 +512,7 @@ struct pt_scene {
 	// paths (outside the image) that each of them carried in its first queue
 	struct counter_read { uint32_t* counters; uint32_t padding_paths; };
 	std::vector<counter_read> pending_counter_reads;
+	std::vector<uint32_t*> snapshot_pool; // pinned buffers of PT_COUNTER_WORDS words, reused
 };
 
 // ext_count[k] and shadow_count[k] per bounce, then 8 fetch counters for each of the possible trace launches of a batch
@@ -608,7 +609,7 @@ static void pt_collect(pt_scene* s) {
 			s->stats.extension_rays += c[k];
 			s->stats.shadow_rays += c[PT_SHADOW_COUNT_OFFSET + k];
 		}
-		hipHostFree(c);
+		s->snapshot_pool.push_back(c);
 	}
 	s->pending_counter_reads.clear();
 }
@@ -932,6 +933,8 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 	pt_collect(s);
 	for (size_t i = 0; i != s->event_pool.size(); ++i)
 		hipEventDestroy(s->event_pool[i]);
+	for (size_t i = 0; i != s->snapshot_pool.size(); ++i)
+		hipHostFree(s->snapshot_pool[i]);
 	pt_free_render_targets(s);
 	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->shade_tris); hipFree(s->materials); hipFree(s->textures); hipFree(s->texture_table); hipFree(s->texture_blob);
 	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->nodes); hipFree(s->tris);
@@ -1083,7 +1086,12 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 	}
 	// Snapshot the queue sizes of this batch for the ray statistics
 	uint32_t* snapshot = NULL;
-	PT_CHECK(hipHostMalloc((void**) &snapshot, sizeof(uint32_t) * PT_COUNTER_WORDS, hipHostMallocDefault));
+	if (!s->snapshot_pool.empty()) {
+		snapshot = s->snapshot_pool.back();
+		s->snapshot_pool.pop_back();
+	}
+	else
+		PT_CHECK(hipHostMalloc((void**) &snapshot, sizeof(uint32_t) * PT_COUNTER_WORDS, hipHostMallocDefault));
 	PT_CHECK(hipMemcpyAsync(snapshot, s->counters, sizeof(uint32_t) * PT_COUNTER_WORDS, hipMemcpyDeviceToHost, s->stream));
 	pt_scene::counter_read read = { snapshot, path_count - s->width * s->height * frame_count };
 	s->pending_counter_reads.push_back(read);

@@ -497,8 +497,13 @@ struct pt_scene {
 	uint32_t* counters; // ext_count[], shadow_count[] at PT_SHADOW_COUNT_OFFSET, then the fetch counters
 	PtConstants* constants;
 	u32x2* stack_overflow;
+	u32x2* stack_overflow_shadow; // the shadow traversal may run beside the extension traversal
 	uint32_t stack_capacity, stack_overflow_stride;
 	uint32_t trace_grid; // blocks of the persistent traversal kernels
+	// Shadow rays of vertex k and extension rays of vertex k + 1 are independent:
+	// the former run on a stream of their own, joined before the next shading
+	hipStream_t shadow_stream;
+	hipEvent_t shade_done, shadow_done;
 	unsigned long long* visit_counters;
 	// pinned host staging for counter readback
 	uint32_t* host_counters;
@@ -533,9 +538,11 @@ static uint32_t pt_grid_chunked(uint64_t capacity, uint32_t block_size = PT_BLOC
 // Workgroups for a traversal launch over at most ray_count rays. A launch
 // ends when its last wave has finished its last ray, so a short queue (one
 // 1080p frame is 2 M rays, four per lane of the full grid) is done sooner by
-// one workgroup per CU than by two: measured 4.0 instead of 3.5 Grays/s.
+// one workgroup per CU than by two, and leaves room for a second traversal
+// kernel beside it. Measured at 1080p: faster up to four frames per batch
+// (8 M paths), slower from eight on.
 static uint32_t pt_trace_grid(const pt_scene* s, uint64_t ray_count) {
-	if (ray_count < (4ull << 20))
+	if (ray_count < (12ull << 20))
 		return s->trace_grid / PT_TRACE_BLOCKS_PER_CU;
 	return s->trace_grid;
 }
@@ -572,18 +579,19 @@ struct pt_launch_timer {
 	pt_scene* s;
 	int kind;
 	hipEvent_t begin, end;
-	pt_launch_timer(pt_scene* scene, int kind_) : s(scene), kind(kind_), begin(NULL), end(NULL) {
+	hipStream_t stream;
+	pt_launch_timer(pt_scene* scene, int kind_, hipStream_t stream_ = NULL) : s(scene), kind(kind_), begin(NULL), end(NULL), stream(stream_ ? stream_ : scene->stream) {
 		++s->stats.kernel_launches[kind];
 		if (s->timing_enabled) {
 			begin = pt_get_event(s);
 			end = pt_get_event(s);
 			if (begin && end)
-				hipEventRecord(begin, s->stream);
+				hipEventRecord(begin, stream);
 		}
 	}
 	~pt_launch_timer() {
 		if (begin && end) {
-			hipEventRecord(end, s->stream);
+			hipEventRecord(end, stream);
 			pt_scene::timed_launch t = { kind, begin, end };
 			s->pending_events.push_back(t);
 		}
@@ -831,13 +839,14 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 	s->accum = NULL;
 	s->sample_count = 0;
 	memset(&s->wf, 0, sizeof(s->wf));
-	s->counters = NULL; s->constants = NULL; s->stack_overflow = NULL; s->visit_counters = NULL; s->host_counters = NULL;
+	s->counters = NULL; s->constants = NULL; s->stack_overflow = NULL; s->stack_overflow_shadow = NULL; s->shadow_stream = NULL; s->shade_done = NULL; s->shadow_done = NULL; s->visit_counters = NULL; s->host_counters = NULL;
 	s->stack_capacity = s->stack_overflow_stride = s->trace_grid = 0;
 	s->timing_enabled = s->visit_counters_enabled = 0;
 	memset(&s->stats, 0, sizeof(s->stats));
 	int failed = 1;
 	do {
-		if (hipStreamCreate(&s->stream) != hipSuccess)
+		if (hipStreamCreate(&s->stream) != hipSuccess || hipStreamCreate(&s->shadow_stream) != hipSuccess
+			|| hipEventCreateWithFlags(&s->shade_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->shadow_done, hipEventDisableTiming) != hipSuccess)
 			break;
 		uint64_t n = s->triangle_count;
 		if (pt_alloc(&s->positions, 3 * n) || pt_alloc(&s->normals_uvs, 3 * n) || pt_alloc(&s->shade_tris, n) || pt_alloc(&s->materials, n)
@@ -911,7 +920,8 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 		if (s->stack_capacity < PT_WAVE_STACK + 1)
 			s->stack_capacity = PT_WAVE_STACK + 1;
 		s->stack_overflow_stride = s->trace_grid * PT_TRACE_BLOCK;
-		if (pt_alloc(&s->stack_overflow, (uint64_t) s->stack_overflow_stride * (s->stack_capacity - PT_WAVE_STACK)))
+		if (pt_alloc(&s->stack_overflow, (uint64_t) s->stack_overflow_stride * (s->stack_capacity - PT_WAVE_STACK))
+			|| pt_alloc(&s->stack_overflow_shadow, (uint64_t) s->stack_overflow_stride * (s->stack_capacity - PT_WAVE_STACK)))
 			break;
 		failed = 0;
 	} while (0);
@@ -928,6 +938,8 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 	if (!s)
 		return;
 	hipSetDevice(s->device);
+	if (s->shadow_stream)
+		hipStreamSynchronize(s->shadow_stream);
 	if (s->stream)
 		hipStreamSynchronize(s->stream);
 	pt_collect(s);
@@ -938,7 +950,11 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 	pt_free_render_targets(s);
 	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->shade_tris); hipFree(s->materials); hipFree(s->textures); hipFree(s->texture_table); hipFree(s->texture_blob);
 	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->nodes); hipFree(s->tris);
-	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters); hipFree(s->stack_overflow);
+	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters); hipFree(s->stack_overflow); hipFree(s->stack_overflow_shadow);
+	if (s->shade_done) hipEventDestroy(s->shade_done);
+	if (s->shadow_done) hipEventDestroy(s->shadow_done);
+	if (s->shadow_stream)
+		hipStreamDestroy(s->shadow_stream);
 	if (s->stream)
 		hipStreamDestroy(s->stream);
 	delete s;
@@ -1015,7 +1031,7 @@ static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity, 
 	a.scene = pt_scene_view(s);
 	a.wf = s->wf;
 	a.constants = s->constants;
-	a.stack_overflow = s->stack_overflow;
+	a.stack_overflow = shadow ? s->stack_overflow_shadow : s->stack_overflow;
 	a.stack_overflow_stride = s->stack_overflow_stride;
 	a.stack_capacity = s->stack_capacity;
 	a.bounce = bounce;
@@ -1050,8 +1066,19 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count, s->path_length ? path_count : 0u);
 	}
 	uint32_t parity = 0;
+	// Short queues get one traversal workgroup per CU, so the shadow rays of a
+	// vertex and the extension rays of the next fit on the chip side by side;
+	// long queues fill it alone and stay on one stream
+	const bool overlap = pt_trace_grid(s, path_count) < s->trace_grid;
+	hipStream_t shadow_stream = overlap ? s->shadow_stream : s->stream;
+	bool shadow_pending = false;
 	for (uint32_t k = 1; k <= s->path_length; ++k) {
 		pt_launch_trace_extension(s, k - 1, parity, path_count);
+		// Shading vertex k adds to the radiance after the light sample of vertex k - 1
+		if (shadow_pending) {
+			PT_CHECK(hipStreamWaitEvent(s->stream, s->shadow_done, 0));
+			shadow_pending = false;
+		}
 		{
 			pt_launch_timer timer(s, PT_K_SHADE);
 			PtShadeArgs a;
@@ -1071,15 +1098,27 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 			}
 		}
 		if (s->strategy == PT_STRATEGY_NEE && k < s->path_length) {
-			pt_launch_timer timer(s, PT_K_TRACE_SHADOW);
-			PtTraceArgs a = pt_trace_args(s, k, 0, true);
-			if (s->visit_counters_enabled)
-				hipLaunchKernelGGL(k_trace_shadow<true>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
-			else
-				hipLaunchKernelGGL(k_trace_shadow<false>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+			if (overlap) {
+				PT_CHECK(hipEventRecord(s->shade_done, s->stream));
+				PT_CHECK(hipStreamWaitEvent(shadow_stream, s->shade_done, 0));
+			}
+			{
+				pt_launch_timer timer(s, PT_K_TRACE_SHADOW, shadow_stream);
+				PtTraceArgs a = pt_trace_args(s, k, 0, true);
+				if (s->visit_counters_enabled)
+					hipLaunchKernelGGL(k_trace_shadow<true>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, shadow_stream, a);
+				else
+					hipLaunchKernelGGL(k_trace_shadow<false>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, shadow_stream, a);
+			}
+			if (overlap) {
+				PT_CHECK(hipEventRecord(s->shadow_done, shadow_stream));
+				shadow_pending = true;
+			}
 		}
 		parity ^= 1;
 	}
+	if (shadow_pending)
+		PT_CHECK(hipStreamWaitEvent(s->stream, s->shadow_done, 0));
 	{
 		pt_launch_timer timer(s, PT_K_RESOLVE);
 		hipLaunchKernelGGL(k_resolve, dim3(pt_grid(batch.paths_per_frame)), dim3(PT_BLOCK), 0, s->stream, batch, s->wf, s->accum, overwrite_first);

@@ -56,6 +56,7 @@ def parse_args():
     p.add_argument("--spp-per-step", type=int, default=32)
     p.add_argument("--path-length", type=int, default=4)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--force-collectives", action="store_true", help="take the multi-GPU code path (process group, all-reduce) even with one rank")
     p.add_argument("--workload", choices=sorted(WORKLOADS), default="cornell",
                    help="cornell: the reference's own scene file; city / interior: generated stand-ins for Bistro exterior / Arcade")
     p.add_argument("--triangles", type=int, default=None, help="triangle budget of a generated workload")
@@ -118,10 +119,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world_size > 1:
+    distributed = world_size > 1 or args.force_collectives
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
 
-    root = workload_root(args, rank, dist.barrier if world_size > 1 else None)
+    root = workload_root(args, rank, dist.barrier if distributed else None)
     name, _, save, label, _ = WORKLOADS[args.workload]
     spec = host_api.quickload(os.path.join(root, "data", "saves", save))
     renderer = host_api.Renderer(spec, root, device=local_rank, width=args.width, height=args.height,
@@ -144,7 +148,7 @@ def main():
     def barrier():
         renderer.synchronize()
         torch.cuda.synchronize()
-        if world_size > 1:
+        if distributed:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -158,7 +162,7 @@ def main():
     for _ in range(args.warmup):
         render_step(True)
     tensor = multi_gpu.accumulation_tensor(renderer)
-    if world_size > 1:
+    if distributed:
         dist.all_reduce(tensor)  # warm up the communicator
     renderer.set_instrumentation(kernel_timing=True, visit_counters=False)
     renderer.reset_statistics()
@@ -172,7 +176,7 @@ def main():
     stats = renderer.statistics()
     rays = stats.extension_rays + stats.shadow_rays
     totals = torch.tensor([float(rays), float(stats.paths), seconds], dtype=torch.float64, device="cuda")
-    if world_size > 1:
+    if distributed:
         maximum = totals.clone()
         dist.all_reduce(totals, op=dist.ReduceOp.SUM)
         dist.all_reduce(maximum, op=dist.ReduceOp.MAX)
@@ -223,7 +227,7 @@ def main():
         C.CDLL(None).fflush(None)
         os.write(json_fd, (json.dumps(result) + "\n").encode())
     renderer.close()
-    if world_size > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

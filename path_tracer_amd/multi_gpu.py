@@ -45,7 +45,7 @@ def all_reduce_accumulation(renderer, total_sample_count=None):
     import torch.distributed as dist
     renderer.synchronize()
     tensor = accumulation_tensor(renderer)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         # The alpha channel holds 1 on every rank; keep it 1 after the sum
         dist.all_reduce(tensor, op=dist.ReduceOp.SUM)
         tensor[..., 3] = 1.0

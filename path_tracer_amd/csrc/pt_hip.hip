@@ -17,6 +17,9 @@
 #include "pt_shade.h"
 #include "pt_trace_wave.h"
 
+#ifndef PT_SHORT_BATCH_PATHS
+#define PT_SHORT_BATCH_PATHS (12ull << 20) // batches below this get one traversal workgroup per CU and two streams
+#endif
 #ifndef PT_BATCH_TARGET_PATHS
 #define PT_BATCH_TARGET_PATHS (64ull << 20)
 #endif
@@ -542,7 +545,7 @@ static uint32_t pt_grid_chunked(uint64_t capacity, uint32_t block_size = PT_BLOC
 // kernel beside it. Measured at 1080p: faster up to four frames per batch
 // (8 M paths), slower from eight on.
 static uint32_t pt_trace_grid(const pt_scene* s, uint64_t ray_count) {
-	if (ray_count < (12ull << 20))
+	if (ray_count < PT_SHORT_BATCH_PATHS)
 		return s->trace_grid / PT_TRACE_BLOCKS_PER_CU;
 	return s->trace_grid;
 }

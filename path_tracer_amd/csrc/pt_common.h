@@ -179,9 +179,9 @@ struct PtTexture {
 };
 
 // What the shading kernels read per texture, small enough that the table of a
-// whole scene (at most 768 textures) stays in the vector L1: the offset of mip
-// 0 in the blob in units of 16 bytes, and log2 width | log2 height << 8 |
-// VkFormat << 16
+// whole scene (at most 768 textures) stays in the vector L1: the offset of
+// the texture's texels in the blob in units of 16 bytes (PtTexture.mip_offsets[0]
+// holds it), and log2 width | log2 height << 8 | VkFormat << 16
 PT_FN u32x2 pt_pack_texture(const PtTexture& t) {
 	uint32_t log_w = 0, log_h = 0;
 	while ((1u << log_w) < t.width) ++log_w;
@@ -209,7 +209,7 @@ struct PtSceneView {
 	const PtShadeTri* shade_tris; // mesh data as stored in the .vks file, regrouped per triangle
 	const uint8_t* materials;   // 1 per triangle
 	const u32x2* texture_table; // 3 per material, see pt_pack_texture()
-	const uint8_t* texture_blob;
+	const uint8_t* texture_blob; // decoded texels of all textures, see pt_fetch_texel()
 	const float* srgb_to_linear; // 256 entries
 	const f32x4* lights;
 	uint32_t light_count;

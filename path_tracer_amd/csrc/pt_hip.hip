@@ -274,6 +274,16 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_shadow(PtTraceArgs a) 
 		});
 }
 
+// Decodes mip 0 of one BC1 / BC5 texture into tiled 8-bit texels (pt_fetch_texel() reads them)
+__global__ void __launch_bounds__(PT_BLOCK) k_decode_texture(const uint8_t* bc_mip_0, uint32_t* texels, uint32_t packed_info, uint32_t texel_count) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i >= texel_count)
+		return;
+	uint32_t log_w = packed_info & 0xffu, format = packed_info >> 16;
+	uint32_t x = i & ((1u << log_w) - 1u), y = i >> log_w;
+	texels[pt_texel_index(log_w, x, y)] = pt_decode_texel(bc_mip_0, log_w, format, x, y);
+}
+
 // The three .vks arrays of a triangle side by side in one 64-byte record
 __global__ void __launch_bounds__(PT_BLOCK) k_build_shade_tris(const u32x2* positions, const u32x2* normals_uvs, const uint8_t* materials, PtShadeTri* shade_tris, uint32_t triangle_count) {
 	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
@@ -287,6 +297,13 @@ __global__ void __launch_bounds__(PT_BLOCK) k_build_shade_tris(const u32x2* posi
 	t.material = materials[i];
 	t.pad[0] = t.pad[1] = t.pad[2] = 0;
 	shade_tris[i] = t;
+}
+
+// Copies the sRGB table into LDS for pt_srgb_to_linear(); all threads of the workgroup take part
+__device__ __forceinline__ void pt_stage_srgb_table(const float* table) {
+	for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x)
+		pt_srgb_table_lds[i] = table[i];
+	__syncthreads();
 }
 
 struct PtShadeArgs {
@@ -308,6 +325,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(PtShadeArgs a) {
 	uint32_t count = a.wf.ext_count[a.k - 1];
 	if (!pt_block_first_slot(count, &first_slot, PT_SHADE_BLOCK))
 		return;
+	pt_stage_srgb_table(a.scene.srgb_to_linear);
 	// Per-light importances of this thread's vertex between the two loops of
 	// pt_sample_lights(): lane-contiguous, hence free of bank conflicts
 	__shared__ float light_importances[(STRATEGY == PT_STRATEGY_NEE) ? PT_LIGHT_CACHE_SIZE * PT_SHADE_BLOCK : 1];
@@ -437,6 +455,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_user_rays(PtUserRayArg
 }
 
 __global__ void __launch_bounds__(PT_BLOCK) k_shading_data(PtSceneView scene, const PtConstants* constants, const int32_t* triangles, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out) {
+	pt_stage_srgb_table(scene.srgb_to_linear);
 	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
 	if (i >= count)
 		return;
@@ -478,7 +497,6 @@ struct pt_scene {
 	PtShadeTri* shade_tris;
 	uint8_t* materials;
 	u32x2* texture_table;
-	PtTexture* textures;
 	uint8_t* texture_blob;
 	float* srgb_to_linear;
 	f32x4* lights;
@@ -829,7 +847,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 	s->triangle_count = (uint32_t) header->triangle_count;
 	s->material_count = (uint32_t) header->material_count;
 	s->texture_count = texture_count;
-	s->positions = NULL; s->normals_uvs = NULL; s->shade_tris = NULL; s->materials = NULL; s->textures = NULL; s->texture_table = NULL; s->texture_blob = NULL;
+	s->positions = NULL; s->normals_uvs = NULL; s->shade_tris = NULL; s->materials = NULL; s->texture_table = NULL; s->texture_blob = NULL;
 	s->srgb_to_linear = NULL; s->lights = NULL; s->light_count = 0; s->nodes = NULL; s->tris = NULL;
 	memset(&s->bvh_info, 0, sizeof(s->bvh_info));
 	s->strategy = PT_STRATEGY_NEE;
@@ -872,37 +890,43 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 		}
 		if (hipMemcpyAsync(s->srgb_to_linear, table, sizeof(table), hipMemcpyHostToDevice, s->stream) != hipSuccess)
 			break;
-		// Pack all mip payloads into one blob, each on a 16-byte boundary
+		// The texels of all textures decoded into one blob (pt_fetch_texel()):
+		// the block-compressed mip 0 payloads go to the GPU, a kernel decodes them
 		std::vector<PtTexture> descs(texture_count ? texture_count : 1);
-		uint64_t blob_size = 0;
+		std::vector<uint64_t> bc_offsets(texture_count ? texture_count : 1);
+		uint64_t texel_bytes = 0, bc_bytes = 0;
 		for (uint32_t i = 0; i != texture_count; ++i) {
 			descs[i].width = textures[i].width;
 			descs[i].height = textures[i].height;
 			descs[i].format = textures[i].format;
-			descs[i].mip_count = textures[i].mip_count;
-			for (uint32_t m = 0; m != textures[i].mip_count; ++m) {
-				descs[i].mip_offsets[m] = blob_size;
-				blob_size += (textures[i].mip_sizes[m] + 15) & ~15ull;
-			}
+			descs[i].mip_count = 1;
+			descs[i].mip_offsets[0] = texel_bytes;
+			texel_bytes += (uint64_t) textures[i].width * textures[i].height * 4;
+			bc_offsets[i] = bc_bytes;
+			bc_bytes += (textures[i].mip_sizes[0] + 15) & ~15ull;
 		}
-		std::vector<uint8_t> blob(blob_size ? blob_size : 16);
+		std::vector<uint8_t> bc_blob(bc_bytes ? bc_bytes : 16);
 		for (uint32_t i = 0; i != texture_count; ++i)
-			for (uint32_t m = 0; m != textures[i].mip_count; ++m)
-				if (textures[i].mip_data[m])
-					memcpy(&blob[descs[i].mip_offsets[m]], textures[i].mip_data[m], textures[i].mip_sizes[m]);
+			memcpy(&bc_blob[bc_offsets[i]], textures[i].mip_data[0], textures[i].mip_sizes[0]);
 		std::vector<u32x2> packed(descs.size());
 		for (size_t i = 0; i != descs.size(); ++i)
 			packed[i] = (i < texture_count) ? pt_pack_texture(descs[i]) : u32x2{ 0u, 0u };
-		if (blob.size() >> 36) {
-			printf("The textures take %llu bytes, more than the 64 GiB that a scene may hold.\n", (unsigned long long) blob.size());
+		if (texel_bytes >> 36) {
+			printf("The textures take %llu bytes decoded, more than the 64 GiB that a scene may hold.\n", (unsigned long long) texel_bytes);
 			break;
 		}
-		if (pt_alloc(&s->texture_blob, blob.size()) || pt_alloc(&s->textures, descs.size()) || pt_alloc(&s->texture_table, packed.size()))
-			break;
-		if (hipMemcpyAsync(s->texture_blob, blob.data(), blob.size(), hipMemcpyHostToDevice, s->stream) != hipSuccess
-			|| hipMemcpyAsync(s->textures, descs.data(), descs.size() * sizeof(PtTexture), hipMemcpyHostToDevice, s->stream) != hipSuccess
-			|| hipMemcpyAsync(s->texture_table, packed.data(), packed.size() * sizeof(u32x2), hipMemcpyHostToDevice, s->stream) != hipSuccess
-			|| hipStreamSynchronize(s->stream) != hipSuccess)
+		uint8_t* device_bc_blob = NULL;
+		bool textures_failed = pt_alloc(&s->texture_blob, texel_bytes ? texel_bytes : 16) || pt_alloc(&device_bc_blob, bc_blob.size()) || pt_alloc(&s->texture_table, packed.size())
+			|| hipMemcpyAsync(device_bc_blob, bc_blob.data(), bc_blob.size(), hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(s->texture_table, packed.data(), packed.size() * sizeof(u32x2), hipMemcpyHostToDevice, s->stream) != hipSuccess;
+		for (uint32_t i = 0; i != texture_count && !textures_failed; ++i) {
+			uint32_t texels = textures[i].width * textures[i].height;
+			hipLaunchKernelGGL(k_decode_texture, dim3(pt_grid(texels)), dim3(PT_BLOCK), 0, s->stream,
+				device_bc_blob + bc_offsets[i], (uint32_t*) (s->texture_blob + descs[i].mip_offsets[0]), packed[i].y, texels);
+		}
+		textures_failed = textures_failed || hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess;
+		hipFree(device_bc_blob);
+		if (textures_failed)
 			break;
 		if (pt_build_bvh(s, header))
 			break;
@@ -951,7 +975,7 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 	for (size_t i = 0; i != s->snapshot_pool.size(); ++i)
 		hipHostFree(s->snapshot_pool[i]);
 	pt_free_render_targets(s);
-	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->shade_tris); hipFree(s->materials); hipFree(s->textures); hipFree(s->texture_table); hipFree(s->texture_blob);
+	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->shade_tris); hipFree(s->materials); hipFree(s->texture_table); hipFree(s->texture_blob);
 	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->nodes); hipFree(s->tris);
 	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters); hipFree(s->stack_overflow); hipFree(s->stack_overflow_shadow);
 	if (s->shade_done) hipEventDestroy(s->shade_done);

@@ -140,8 +140,8 @@ PT_FN v3 pt_dequantize_normal(float ox, float oy) {
 
 // ---- texture(): shading_data.glsl:74-76 with the sampler of
 // src/main.c:864-873 (linear filtering, REPEAT addressing). Blocks are decoded
-// by hand with 8-bit integer palettes; filtering is bilinear on mip 0 with
-// float weights. ----
+// by hand with 8-bit integer palettes (once per scene, see below); filtering is
+// bilinear on mip 0 with float weights. ----
 
 // BC1 block (two RGB565 endpoints + 16 2-bit codes) -> 8-bit RGB of one texel
 PT_FN void pt_decode_bc1(uint32_t w0, uint32_t w1, uint32_t px, uint32_t py, uint32_t* r, uint32_t* g, uint32_t* b) {
@@ -175,24 +175,54 @@ PT_FN uint32_t pt_decode_bc4(uint32_t w0, uint32_t w1, uint32_t px, uint32_t py)
 	return ((6 - code) * a0 + (code - 1) * a1) / 5;
 }
 
-// Mip payloads start on 16-byte boundaries of the blob, so blocks can be
-// read with aligned 8- and 16-byte loads
-PT_FN v3 pt_fetch_texel(const PtSceneView& s, u32x2 t, int32_t x, int32_t y) {
-	uint32_t log_w = t.y & 0xffu, log_h = (t.y >> 8) & 0xffu, format = t.y >> 16;
-	uint32_t ux = (uint32_t) x & ((1u << log_w) - 1u), uy = (uint32_t) y & ((1u << log_h) - 1u);
-	uint64_t block = ((uint64_t) (uy / 4) << (log_w - 2)) + ux / 4;
-	const uint8_t* mip_0 = s.texture_blob + ((uint64_t) t.x << 4);
+// Textures are decoded once, when a scene is created, into 8-bit texels of
+// four bytes (R, G, B, 0) in tiles of 4x4 texels, one 64-byte line per tile as
+// in the block-compressed original: the decode is exact integer arithmetic,
+// so sampling the decoded texels gives the same values as decoding per
+// sample, at a fifth of the instructions (shading is bound by them) and eight
+// times the memory of BC1, which 288 GB of HBM can afford. Mip 0 only.
+PT_FN uint64_t pt_texel_index(uint32_t log_w, uint32_t x, uint32_t y) {
+	return ((((uint64_t) (y >> 2) << (log_w - 2)) + (x >> 2)) << 4) + ((y & 3u) << 2) + (x & 3u);
+}
+
+// Texel (x, y) of mip 0 of a BC1 (formats 131, 132) or BC5 (141) texture
+PT_FN uint32_t pt_decode_texel(const uint8_t* mip_0, uint32_t log_w, uint32_t format, uint32_t x, uint32_t y) {
+	uint64_t block = ((uint64_t) (y / 4) << (log_w - 2)) + x / 4;
 	if (format == 141) {
 		u32x4 w = *(const u32x4*) (mip_0 + block * 16);
-		uint32_t r = pt_decode_bc4(w.x, w.y, ux & 3, uy & 3);
-		uint32_t g = pt_decode_bc4(w.z, w.w, ux & 3, uy & 3);
-		return mk3(pt_unorm8(r), pt_unorm8(g), 0.0f);
+		uint32_t r = pt_decode_bc4(w.x, w.y, x & 3, y & 3);
+		uint32_t g = pt_decode_bc4(w.z, w.w, x & 3, y & 3);
+		return r | (g << 8);
 	}
 	u32x2 w = *(const u32x2*) (mip_0 + block * 8);
 	uint32_t r, g, b;
-	pt_decode_bc1(w.x, w.y, ux & 3, uy & 3, &r, &g, &b);
+	pt_decode_bc1(w.x, w.y, x & 3, y & 3, &r, &g, &b);
+	return r | (g << 8) | (b << 16);
+}
+
+// The sRGB decoding table (256 floats). A shaded vertex looks up twelve
+// entries; the kernels keep a copy in LDS (pt_stage_srgb_table() at their
+// start), which takes these gathers off the vector memory path that the
+// texel and mesh fetches already keep busy.
+#if defined(__HIPCC__)
+__shared__ float pt_srgb_table_lds[256];
+#endif
+PT_FN float pt_srgb_to_linear(const PtSceneView& s, uint32_t value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	return pt_srgb_table_lds[value];
+#else
+	return s.srgb_to_linear[value];
+#endif
+}
+
+PT_FN v3 pt_fetch_texel(const PtSceneView& s, u32x2 t, int32_t x, int32_t y) {
+	uint32_t log_w = t.y & 0xffu, log_h = (t.y >> 8) & 0xffu, format = t.y >> 16;
+	uint32_t ux = (uint32_t) x & ((1u << log_w) - 1u), uy = (uint32_t) y & ((1u << log_h) - 1u);
+	const uint32_t* texels = (const uint32_t*) (s.texture_blob + ((uint64_t) t.x << 4));
+	uint32_t texel = texels[pt_texel_index(log_w, ux, uy)];
+	uint32_t r = texel & 0xffu, g = (texel >> 8) & 0xffu, b = (texel >> 16) & 0xffu;
 	if (format == 132)
-		return mk3(s.srgb_to_linear[r], s.srgb_to_linear[g], s.srgb_to_linear[b]);
+		return mk3(pt_srgb_to_linear(s, r), pt_srgb_to_linear(s, g), pt_srgb_to_linear(s, b));
 	return mk3(pt_unorm8(r), pt_unorm8(g), pt_unorm8(b));
 }
 

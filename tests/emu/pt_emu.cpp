@@ -161,19 +161,23 @@ EmuScene* emu_create_scene(uint64_t material_count, uint64_t triangle_count, con
 		s->srgb[i] = (float) ((c <= 0.04045) ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
 	}
 	s->textures.resize(texture_count ? texture_count : 1);
+	// As pt_create_scene(): mip 0 of every texture decoded into tiled 8-bit texels
 	for (uint32_t i = 0; i != texture_count; ++i) {
 		const EmuTexture& t = textures[i];
 		PtTexture& d = s->textures[i];
-		d.width = t.width; d.height = t.height; d.format = t.format; d.mip_count = t.mip_count;
+		d.width = t.width; d.height = t.height; d.format = t.format; d.mip_count = 1;
+		size_t offset = s->blob.size();
+		d.mip_offsets[0] = offset;
+		s->blob.resize(offset + (size_t) t.width * t.height * 4);
+		u32x2 packed = pt_pack_texture(d);
+		uint32_t log_w = packed.y & 0xffu;
 		uint32_t block = (t.format == 141) ? 16 : 8;
-		for (uint32_t m = 0; m != t.mip_count; ++m) {
-			uint32_t w = std::max(t.width >> m, 4u), h = std::max(t.height >> m, 4u);
-			uint64_t size = (uint64_t) ((w + 3) / 4) * ((h + 3) / 4) * block;
-			size_t offset = (s->blob.size() + 15) & ~(size_t) 15;
-			s->blob.resize(offset + size);
-			memcpy(&s->blob[offset], t.payload + t.mip_offsets[m], size);
-			d.mip_offsets[m] = offset;
-		}
+		std::vector<uint8_t> aligned((size_t) ((t.width + 3) / 4) * ((t.height + 3) / 4) * block + 16);
+		memcpy(aligned.data(), t.payload + t.mip_offsets[0], aligned.size() - 16);
+		uint32_t* texels = (uint32_t*) &s->blob[offset];
+		for (uint32_t y = 0; y != t.height; ++y)
+			for (uint32_t x = 0; x != t.width; ++x)
+				texels[pt_texel_index(log_w, x, y)] = pt_decode_texel(aligned.data(), log_w, t.format, x, y);
 	}
 	s->blob.resize(s->blob.size() + 16);
 	s->texture_table.resize(s->textures.size());

@@ -550,11 +550,10 @@ PT_FN void pt_build_collapse(const PtBuild& b, float pad, uint32_t wide_index, A
 			out.prim = tri;
 			out.pad[0] = out.pad[1] = 0;
 			b.tris[node.tri_base + tri_offset] = out;
-			node.meta[s] = (uint8_t) (0x20u | tri_offset);
+			node.leafmask |= (uint8_t) (1u << s);
 			++tri_offset;
 		}
 		else {
-			node.meta[s] = (uint8_t) (0x20u | (24u + (uint32_t) s));
 			b.task_binary[node.child_base + inner_offset] = child;
 			++inner_offset;
 		}

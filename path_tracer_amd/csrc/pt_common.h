@@ -128,16 +128,19 @@ static_assert(sizeof(PtConstants) == 784, "constants block must match the refere
 // 8-wide BVH node with child boxes quantised to 8 bits on a per-node
 // power-of-two grid (after Ylitie, Karras, Laine: "Efficient incoherent ray
 // traversal on GPUs through compressed wide BVHs", HPG 2017). 80 bytes.
-// Child i spans origin + q * 2^(e - 127) per axis. meta[i] == 0: empty slot;
-// internal child: 0x20 | (24 + i); leaf child: unary triangle count (1, 3 or
-// 7) << 5 | offset of its first triangle from tri_base (< 24).
+// Child i spans origin + q * 2^(e - 127) per axis. Bit i of imask: child i is
+// an inner node; bit i of leafmask: child i is one triangle; neither: empty
+// slot. Inner children are consecutive nodes from child_base and triangles
+// consecutive from tri_base, both in slot order, so a child's index is the base
+// plus the number of set mask bits below its slot.
 struct alignas(16) PtNode {
 	float origin[3];
 	uint8_t exponent[3];
 	uint8_t imask;
 	uint32_t child_base;
 	uint32_t tri_base;
-	uint8_t meta[8];
+	uint8_t leafmask;
+	uint8_t pad[7];
 	uint8_t qlo[3][8];
 	uint8_t qhi[3][8];
 };

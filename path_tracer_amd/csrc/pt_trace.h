@@ -119,11 +119,10 @@ PT_FN PtHit pt_trace_closest(const PtNode* nodes, const PtTri* tris, uint32_t tr
 			float bx = (pt_as_float(w0.x) - origin.x) * idx, by = (pt_as_float(w0.y) - origin.y) * idy, bz = (pt_as_float(w0.z) - origin.z) * idz;
 			uint32_t qlox[2] = { w2.x, w2.y }, qloy[2] = { w2.z, w2.w }, qloz[2] = { w3.x, w3.y };
 			uint32_t qhix[2] = { w3.z, w3.w }, qhiy[2] = { w4.x, w4.y }, qhiz[2] = { w4.z, w4.w };
-			uint32_t meta[2] = { w1.z, w1.w };
-			uint32_t hitmask = 0;
+			uint32_t leafmask = w1.z & 0xffu;
+			uint32_t hit8 = 0;
 #pragma unroll
 			for (int i = 0; i != 8; ++i) {
-				uint32_t m = (meta[i >> 2] >> (8 * (i & 3))) & 0xffu;
 				float lx = pt_byte_to_float(qlox[i >> 2], i & 3), hx = pt_byte_to_float(qhix[i >> 2], i & 3);
 				float ly = pt_byte_to_float(qloy[i >> 2], i & 3), hy = pt_byte_to_float(qhiy[i >> 2], i & 3);
 				float lz = pt_byte_to_float(qloz[i >> 2], i & 3), hz = pt_byte_to_float(qhiz[i >> 2], i & 3);
@@ -132,22 +131,25 @@ PT_FN PtHit pt_trace_closest(const PtNode* nodes, const PtTri* tris, uint32_t tr
 				float nz = fmaf(neg_z ? hz : lz, az, bz), fz = fmaf(neg_z ? lz : hz, az, bz);
 				float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
 				float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
-				if (m != 0 && tn <= tf) {
-					if (imask & (1u << i))
-						hitmask |= 1u << (24u + ((uint32_t) i ^ octinv));
-					else
-						hitmask |= (m >> 5) << (m & 31u);
-				}
+				if (tn <= tf)
+					hit8 |= 1u << i;
 			}
+			// Inner children in visiting order (slot ^ octinv) in the top byte
+			uint32_t order = 0;
+			for (uint32_t i = 0; i != 8; ++i)
+				if (hit8 & imask & (1u << i))
+					order |= 1u << (i ^ octinv);
 			ngroup.x = w1.x;
-			ngroup.y = (hitmask & 0xff000000u) | imask;
+			ngroup.y = (order << 24) | imask;
+			// Triangles pending in the low byte (by slot), the leaf mask above it
 			tgroup.x = w1.y;
-			tgroup.y = hitmask & 0x00ffffffu;
+			tgroup.y = (hit8 & leafmask) | (leafmask << 8);
 		}
-		while (tgroup.y) {
+		while (tgroup.y & 0xffu) {
 			uint32_t bit = (uint32_t) __builtin_ctz(tgroup.y);
 			tgroup.y &= tgroup.y - 1u;
-			const u32x4* words = (const u32x4*) &tris[tgroup.x + bit];
+			uint32_t rank = (uint32_t) __builtin_popcount((tgroup.y >> 8) & ((1u << bit) - 1u));
+			const u32x4* words = (const u32x4*) &tris[tgroup.x + rank];
 			if (COUNT_VISITS)
 				++visits[1];
 			u32x4 t0 = words[0], t1 = words[1], t2 = words[2];

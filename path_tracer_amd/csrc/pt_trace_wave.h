@@ -246,9 +246,9 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			break;
 
 		if (COUNT_VISITS)
-			node_pass_count += __ballot(active && tgroup.y == 0) != 0;
+			node_pass_count += __ballot(active && (tgroup.y & 0xffu) == 0) != 0;
 		// ---- one node per lane that has no triangles pending ----
-		if (active && tgroup.y == 0) {
+		if (active && (tgroup.y & 0xffu) == 0) {
 			if (!(ngroup.y & 0xff000000u) && sp != 0) {
 				--sp;
 				pt_vec2 entry;
@@ -295,48 +295,45 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				uint32_t nqx[2] = { neg_x ? w3.z : w2.x, neg_x ? w3.w : w2.y }, fqx[2] = { neg_x ? w2.x : w3.z, neg_x ? w2.y : w3.w };
 				uint32_t nqy[2] = { neg_y ? w4.x : w2.z, neg_y ? w4.y : w2.w }, fqy[2] = { neg_y ? w2.z : w4.x, neg_y ? w2.w : w4.y };
 				uint32_t nqz[2] = { neg_z ? w4.z : w3.x, neg_z ? w4.w : w3.y }, fqz[2] = { neg_z ? w3.x : w4.z, neg_z ? w3.y : w4.w };
-				uint32_t meta[2] = { w1.z, w1.w };
-				// A child's meta byte m turns into its bits of the hit mask as
-				// (m >> 5) << (m & 31): the triangles of a leaf child, bit 24 + slot
-				// for an inner child, nothing for an empty slot. No branches: the
-				// eight box tests of a lane run back to back.
-				uint32_t hitmask = 0;
+				uint32_t leafmask = w1.z & 0xffu;
+				// Eight box tests back to back without branches: bit i of hit8 says
+				// whether child slot i was hit (empty slots are masked out below)
+				uint32_t hit8 = 0;
 #pragma unroll
 				for (int i = 0; i != 8; ++i) {
-					uint32_t m = (meta[i >> 2] >> (8 * (i & 3))) & 0xffu;
 					float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bx), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bx);
 					float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, by), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, by);
 					float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bz), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bz);
 					float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
 					float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
-					uint32_t bits = (m >> 5) << (m & 31u);
-					hitmask |= (tn <= tf) ? bits : 0u;
+					hit8 |= (tn <= tf) ? (1u << i) : 0u;
 				}
 				// Inner children: from slot order to visiting order (slot ^ octinv),
 				// three conditional swaps of neighbouring bits, pairs and nibbles
-				uint32_t order = hitmask >> 24;
+				uint32_t order = hit8 & imask;
 				uint32_t swap = ((order >> 1) ^ order) & swap_mask_1;
 				order ^= swap | (swap << 1);
 				swap = ((order >> 2) ^ order) & swap_mask_2;
 				order ^= swap | (swap << 2);
 				swap = ((order >> 4) ^ order) & swap_mask_4;
 				order ^= swap | (swap << 4);
-				hitmask = (hitmask & 0x00ffffffu) | (order << 24);
 				ngroup.x = w1.x;
-				ngroup.y = (hitmask & 0xff000000u) | imask;
+				ngroup.y = (order << 24) | imask;
+				// Triangles pending in the low byte (by slot), the leaf mask above
+				// it: a triangle's index is tri_base plus the leaves below its slot
 				tgroup.x = w1.y;
-				tgroup.y = hitmask & 0x00ffffffu;
+				tgroup.y = (hit8 & leafmask) | (leafmask << 8);
 			}
 		}
 
 		if (COUNT_VISITS)
-			tri_pass_count += __ballot(active && tgroup.y != 0) != 0;
+			tri_pass_count += __ballot(active && (tgroup.y & 0xffu) != 0) != 0;
 		// ---- one triangle per lane that has triangles pending ----
 		for (int round = 0; round != PT_TRIS_PER_PASS; ++round)
-		if (active && tgroup.y != 0) {
+		if (active && (tgroup.y & 0xffu) != 0) {
 			uint32_t bit = (uint32_t) __builtin_ctz(tgroup.y);
 			tgroup.y &= tgroup.y - 1u;
-			uint32_t tri_index = tgroup.x + bit;
+			uint32_t tri_index = tgroup.x + (uint32_t) __builtin_popcount((tgroup.y >> 8) & ((1u << bit) - 1u));
 			if (COUNT_VISITS)
 				++tri_visits;
 			u32x4 t0, t1, t2;
@@ -355,7 +352,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		}
 
 		// ---- retire complete rays ----
-		if (active && !(ngroup.y & 0xff000000u) && sp == 0 && tgroup.y == 0) {
+		if (active && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0) {
 			finish(slot, origin_w, direction_w, hit);
 			active = false;
 		}

@@ -97,6 +97,17 @@ void pt_destroy_scene(pt_scene_t* scene);
  * pt_constants_t is ignored. */
 int pt_set_lights(pt_scene_t* scene, const float* lights, uint32_t count);
 
+/* How next event estimation (sampling strategy 3) chooses its light. EXACT is
+ * the reference's sample_lights() and get_lights_density()
+ * (src/shaders/pathtrace.frag.glsl:120-175): two loops over all lights per
+ * path vertex, selection probability proportional to the solid angle. TREE
+ * has no counterpart in the reference, which truncates to 32 lights
+ * (src/main.c:691-694): one descent through a binary tree over the lights per
+ * vertex, for scenes with thousands of lights; the estimate stays unbiased,
+ * its noise differs. The default is EXACT; the other strategies ignore it. */
+enum { PT_LIGHT_SAMPLING_EXACT = 0, PT_LIGHT_SAMPLING_TREE = 1 };
+int pt_set_light_sampling(pt_scene_t* scene, int light_sampling);
+
 /* Replaces the shader defines SAMPLING_STRATEGY_*, PATH_LENGTH and
  * EMISSION_MATERIAL_INDEX of src/main.c:936-949 (render_settings_t at
  * src/main.h:99-105). path_length is at most 16. */

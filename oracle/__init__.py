@@ -61,6 +61,9 @@ def lib():
         _lib.oracle_render.restype = C.c_uint64
         _lib.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32,
                                        C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_int]
+        _lib.oracle_render_light_sampling.restype = C.c_uint64
+        _lib.oracle_render_light_sampling.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+                                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_int]
         _lib.oracle_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.oracle_rng_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.oracle_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -108,7 +111,8 @@ class OracleScene:
         self.close()
 
     def render(self, constants: Constants, lights, strategy=3, path_length=4, emission_material_index=None,
-               first_frame_index=0, frame_count=1, frame_stride=1, accum=None, threads=1):
+               first_frame_index=0, frame_count=1, frame_stride=1, accum=None, threads=1, light_sampling=0):
+        """light_sampling 0: loops over all lights (the reference); 1: light tree."""
         width, height = int(constants.viewport_size[0]), int(constants.viewport_size[1])
         lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 4)
         accumulate = accum is not None
@@ -116,8 +120,8 @@ class OracleScene:
             accum = np.zeros((height, width, 4), np.float32)
         if emission_material_index is None:
             emission_material_index = self.scene.emission_material_index
-        rays = lib().oracle_render(self.handle, C.byref(constants), _ptr(lights), len(lights), strategy, path_length,
-                                   emission_material_index, first_frame_index, frame_count, frame_stride, int(accumulate), _ptr(accum), threads)
+        rays = lib().oracle_render_light_sampling(self.handle, C.byref(constants), _ptr(lights), len(lights), light_sampling, strategy, path_length,
+                                                  emission_material_index, first_frame_index, frame_count, frame_stride, int(accumulate), _ptr(accum), threads)
         return accum, rays
 
     def primary_hits(self, constants: Constants, frame_index):

@@ -548,6 +548,11 @@ typedef struct {
 	const oracle_constants_t* c;
 	const float* lights;
 	uint32_t light_count;
+	/* Light tree (see build_light_tree()); light_sampling 1 selects it */
+	int light_sampling;
+	const float* light_nodes;
+	const float* tree_lights;
+	uint32_t light_leaf_count;
 	uint32_t path_length;
 	uint32_t emission_material_index;
 	int strategy;
@@ -846,6 +851,227 @@ static float get_lights_density(const context_t* ctx, float total_importance, ve
 	return light_count / (2.0f * M_PI_F * total_importance);
 }
 
+/* ---- Light tree: no counterpart in the reference (it loops over at most 32
+   lights). Restated from the definition the HIP library documents in
+   path_tracer_amd/csrc/pt_light_tree.h, with code of its own: a complete
+   binary tree in heap order whose leaves hold one light or none; a node holds
+   centre and half extents of the box around its spheres, the sum of their
+   squared radii and the squared half diagonal (8 floats). */
+typedef struct {
+	float coordinate;
+	uint32_t index;
+} light_key_t;
+
+static int compare_light_keys(const void* a, const void* b) {
+	const light_key_t* ka = (const light_key_t*) a;
+	const light_key_t* kb = (const light_key_t*) b;
+	if (ka->coordinate != kb->coordinate)
+		return (ka->coordinate < kb->coordinate) ? -1 : 1;
+	return (ka->index < kb->index) ? -1 : ((ka->index > kb->index) ? 1 : 0);
+}
+
+/* Distributes the lights indices[0 .. count) over the slot_count leaf slots
+   of a subtree: split at the median of the centres along the longest axis of
+   their bounding box (lowest axis on ties, lower index on equal coordinates),
+   the larger half to the left */
+static void place_lights(const float* lights, uint32_t* indices, size_t count, float* leaf_lights, size_t slot_count) {
+	if (count == 0)
+		return;
+	if (slot_count == 1) {
+		memcpy(leaf_lights, &lights[4 * (size_t) indices[0]], 4 * sizeof(float));
+		return;
+	}
+	int axis = 0;
+	float longest = -1.0f;
+	for (int a = 0; a != 3; ++a) {
+		float low = lights[4 * (size_t) indices[0] + a], high = low;
+		for (size_t i = 1; i != count; ++i) {
+			float c = lights[4 * (size_t) indices[i] + a];
+			if (c < low) low = c;
+			if (c > high) high = c;
+		}
+		if (high - low > longest) {
+			longest = high - low;
+			axis = a;
+		}
+	}
+	light_key_t* keys = (light_key_t*) malloc(sizeof(light_key_t) * count);
+	for (size_t i = 0; i != count; ++i) {
+		keys[i].coordinate = lights[4 * (size_t) indices[i] + axis];
+		keys[i].index = indices[i];
+	}
+	qsort(keys, count, sizeof(light_key_t), compare_light_keys);
+	for (size_t i = 0; i != count; ++i)
+		indices[i] = keys[i].index;
+	free(keys);
+	size_t left_count = (count + 1) / 2;
+	place_lights(lights, indices, left_count, leaf_lights, slot_count / 2);
+	place_lights(lights, indices + left_count, count - left_count, leaf_lights + 4 * (slot_count / 2), slot_count / 2);
+}
+
+static void build_light_tree(const float* lights, uint32_t count, float** out_nodes, float** out_tree_lights, uint32_t* out_leaf_count) {
+	uint32_t leaf_count = 1;
+	while (leaf_count < count)
+		leaf_count <<= 1;
+	float* nodes = (float*) calloc(16 * (size_t) leaf_count, sizeof(float));
+	float* tree_lights = (float*) calloc(4 * (size_t) leaf_count, sizeof(float));
+	float* lo = (float*) calloc(6 * (size_t) leaf_count, sizeof(float));
+	float* hi = (float*) calloc(6 * (size_t) leaf_count, sizeof(float));
+	uint32_t* indices = (uint32_t*) malloc(sizeof(uint32_t) * (count ? count : 1));
+	for (uint32_t i = 0; i != count; ++i)
+		indices[i] = i;
+	place_lights(lights, indices, count, tree_lights, leaf_count);
+	free(indices);
+	for (size_t j = 0; j != leaf_count; ++j) {
+		const float* l = &tree_lights[4 * j];
+		size_t node = (size_t) leaf_count + j;
+		float radius = fabsf(l[3]);
+		for (int a = 0; a != 3; ++a) {
+			lo[3 * node + a] = l[a] - radius;
+			hi[3 * node + a] = l[a] + radius;
+		}
+		nodes[8 * node + 3] = l[3] * l[3];
+	}
+	for (size_t node = leaf_count - 1; node >= 1; --node) {
+		float power_0 = nodes[8 * (2 * node) + 3], power_1 = nodes[8 * (2 * node + 1) + 3];
+		/* Children without power (empty leaves, radius zero) do not widen the box */
+		float power = 0.0f;
+		int first = 1;
+		for (size_t child = 2 * node; child != 2 * node + 2; ++child) {
+			float child_power = (child == 2 * node) ? power_0 : power_1;
+			if (!(child_power > 0.0f))
+				continue;
+			for (int a = 0; a != 3; ++a) {
+				lo[3 * node + a] = first ? lo[3 * child + a] : fminf(lo[3 * node + a], lo[3 * child + a]);
+				hi[3 * node + a] = first ? hi[3 * child + a] : fmaxf(hi[3 * node + a], hi[3 * child + a]);
+			}
+			power = first ? child_power : (power + child_power);
+			first = 0;
+		}
+		nodes[8 * node + 3] = power;
+	}
+	for (size_t node = 1; node != 2 * (size_t) leaf_count; ++node) {
+		float half[3];
+		for (int a = 0; a != 3; ++a) {
+			nodes[8 * node + a] = 0.5f * (lo[3 * node + a] + hi[3 * node + a]);
+			half[a] = 0.5f * (hi[3 * node + a] - lo[3 * node + a]);
+			nodes[8 * node + 4 + a] = half[a];
+		}
+		nodes[8 * node + 7] = (half[0] * half[0] + half[1] * half[1]) + half[2] * half[2];
+	}
+	free(lo); free(hi);
+	*out_nodes = nodes;
+	*out_tree_lights = tree_lights;
+	*out_leaf_count = leaf_count;
+}
+
+/* Selection weight of a node seen from a shading point: power over squared
+   distance (at least the squared half diagonal), zero below the horizon */
+static float light_node_weight(const context_t* ctx, uint32_t node, vec3 shading_pos, vec3 normal) {
+	const float* n = &ctx->light_nodes[8 * (size_t) node];
+	if (!(n[3] > 0.0f))
+		return 0.0f;
+	vec3 center_dir = sub3(v3(n[0], n[1], n[2]), shading_pos);
+	float reach = (fabsf(normal.x) * n[4] + fabsf(normal.y) * n[5]) + fabsf(normal.z) * n[6];
+	if (dot3(normal, center_dir) + reach < 0.0f)
+		return 0.0f;
+	return n[3] / fmaxf(dot3(center_dir, center_dir), n[7]);
+}
+
+static vec3 sample_lights_tree(const context_t* ctx, float* out_density, vec3 shading_pos, vec3 normal, vec2 randoms) {
+	*out_density = 0.0f;
+	uint32_t node = 1;
+	float probability = 1.0f;
+	while (node < ctx->light_leaf_count) {
+		float w0 = light_node_weight(ctx, 2 * node, shading_pos, normal);
+		float w1 = light_node_weight(ctx, 2 * node + 1, shading_pos, normal);
+		float total = w0 + w1;
+		if (!(total > 0.0f))
+			return v3(0.0f, 0.0f, 0.0f);
+		float target = randoms.x * total;
+		if (target < w0 || !(w1 > 0.0f)) {
+			randoms.x = fminf(1.0f, target / w0);
+			probability *= w0 / total;
+			node = 2 * node;
+		}
+		else {
+			randoms.x = fminf(1.0f, (target - w0) / w1);
+			probability *= w1 / total;
+			node = 2 * node + 1;
+		}
+	}
+	const float* l = &ctx->tree_lights[4 * (size_t) (node - ctx->light_leaf_count)];
+	float importance = get_spherical_light_importance(v3(l[0], l[1], l[2]), l[3], shading_pos, normal);
+	if (!(importance > 0.0f))
+		return v3(0.0f, 0.0f, 0.0f);
+	*out_density = probability / ((2.0f * M_PI_F) * importance);
+	return sample_spherical_light(v3(l[0], l[1], l[2]), importance, shading_pos, randoms);
+}
+
+/* Probability of the descent above ending at the given leaf node */
+static float light_selection_probability(const context_t* ctx, uint32_t leaf_node, vec3 shading_pos, vec3 normal) {
+	uint32_t depth = 0;
+	while ((leaf_node >> depth) > 1)
+		++depth;
+	float probability = 1.0f;
+	for (uint32_t level = 1; level <= depth; ++level) {
+		uint32_t node = leaf_node >> (depth - level);
+		float w0 = light_node_weight(ctx, node & ~1u, shading_pos, normal);
+		float w1 = light_node_weight(ctx, node | 1u, shading_pos, normal);
+		float w = (node & 1u) ? w1 : w0;
+		if (!(w > 0.0f))
+			return 0.0f;
+		probability *= w / (w0 + w1);
+	}
+	return probability;
+}
+
+/* Adds to *density, for every light below node that a ray from shading_pos
+   along dir meets (test of :160-170), selection probability times cone
+   density; left subtree first */
+static void accumulate_tree_density(const context_t* ctx, uint32_t node, vec3 shading_pos, vec3 normal, vec3 dir, float* density) {
+	const float* n = &ctx->light_nodes[8 * (size_t) node];
+	if (!(n[3] > 0.0f))
+		return;
+	if (node >= ctx->light_leaf_count) {
+		const float* l = &ctx->tree_lights[4 * (size_t) (node - ctx->light_leaf_count)];
+		vec3 center_dir = sub3(v3(l[0], l[1], l[2]), shading_pos);
+		float center_dist_2 = dot3(center_dir, center_dir);
+		float center_dot_dir = dot3(center_dir, dir);
+		float in_sphere = center_dist_2 - l[3] * l[3];
+		float discriminant = center_dot_dir * center_dot_dir - in_sphere;
+		if (discriminant >= 0.0f && in_sphere >= 0.0f && center_dot_dir >= 0.0f) {
+			float importance = get_spherical_light_importance(v3(l[0], l[1], l[2]), l[3], shading_pos, normal);
+			if (importance > 0.0f)
+				*density += light_selection_probability(ctx, node, shading_pos, normal) / ((2.0f * M_PI_F) * importance);
+		}
+		return;
+	}
+	/* Skip the subtree unless the ray meets its box (slab test), widened a
+	   little against rounding */
+	float t_near = 0.0f, t_far = INFINITY;
+	const float p[3] = { shading_pos.x, shading_pos.y, shading_pos.z }, d[3] = { dir.x, dir.y, dir.z };
+	for (int a = 0; a != 3; ++a) {
+		float safe = (fabsf(d[a]) > 1.0e-30f) ? d[a] : copysignf(1.0e-30f, d[a]);
+		float inv = 1.0f / safe;
+		float offset = n[a] - p[a];
+		float reach = fmaf(n[4 + a], 1.0001f, 4.0e-7f * fabsf(offset));
+		float t0 = (offset - reach) * inv, t1 = (offset + reach) * inv;
+		t_near = fmaxf(t_near, fminf(t0, t1));
+		t_far = fminf(t_far, fmaxf(t0, t1));
+	}
+	if (t_near <= t_far) {
+		accumulate_tree_density(ctx, 2 * node, shading_pos, normal, dir, density);
+		accumulate_tree_density(ctx, 2 * node + 1, shading_pos, normal, dir, density);
+	}
+}
+
+static float get_lights_density_tree(const context_t* ctx, vec3 shading_pos, vec3 normal, vec3 sampled_dir) {
+	float density = 0.0f;
+	accumulate_tree_density(ctx, 1, shading_pos, normal, sampled_dir, &density);
+	return density;
+}
+
 /* :181-199 */
 static int trace_ray(context_t* ctx, shading_data_t* out, vec3 ray_origin, vec3 ray_dir) {
 	++ctx->ray_count;
@@ -928,12 +1154,18 @@ static vec3 path_trace_nee(context_t* ctx, vec3 ray_origin, vec3 ray_dir, uint32
 		int hit = trace_ray(ctx, &s, ray_origin, ray_dir);
 		radiance = add3(radiance, mul3(nee_throughput_weight, s.emission));
 		if (hit && k < ctx->path_length) {
-			float total_light_importance;
-			vec3 light_dir = sample_lights(ctx, &total_light_importance, s.pos, s.normal, get_random_numbers(seed));
+			float total_light_importance = 0.0f, sampled_light_density = 0.0f;
+			vec3 light_dir = ctx->light_sampling
+				? sample_lights_tree(ctx, &sampled_light_density, s.pos, s.normal, get_random_numbers(seed))
+				: sample_lights(ctx, &total_light_importance, s.pos, s.normal, get_random_numbers(seed));
 			float lambert_in_0 = dot3(s.normal, light_dir);
 			if (lambert_in_0 > 0.0f) {
 				vec3 light_emission = trace_ray_emission(ctx, s.pos, light_dir);
-				float light_density_0 = get_lights_density(ctx, total_light_importance, s.pos, s.normal, light_dir, 1);
+				/* With the tree the sampled light counts even if rounding lets
+				   its own ray miss it, like max(1, count) at :172-173 */
+				float light_density_0 = ctx->light_sampling
+					? fmaxf(get_lights_density_tree(ctx, s.pos, s.normal, light_dir), sampled_light_density)
+					: get_lights_density(ctx, total_light_importance, s.pos, s.normal, light_dir, 1);
 				float brdf_density_0 = get_frostbite_brdf_density(&s, light_dir);
 				vec3 weight = mul3(mul3(throughput_weight, frostbite_brdf(&s, light_dir)), light_emission);
 				radiance = add3(radiance, scale3(weight, lambert_in_0 / (light_density_0 + brdf_density_0)));
@@ -943,7 +1175,9 @@ static vec3 path_trace_nee(context_t* ctx, vec3 ray_origin, vec3 ray_dir, uint32
 			float lambert_in_1 = dot3(s.normal, ray_dir);
 			if (lambert_in_1 <= 0.0f)
 				break;
-			float light_density_1 = get_lights_density(ctx, total_light_importance, s.pos, s.normal, ray_dir, 0);
+			float light_density_1 = ctx->light_sampling
+				? get_lights_density_tree(ctx, s.pos, s.normal, ray_dir)
+				: get_lights_density(ctx, total_light_importance, s.pos, s.normal, ray_dir, 0);
 			float brdf_density_1 = get_frostbite_brdf_density(&s, ray_dir);
 			vec3 brdf_lambert_1 = scale3(frostbite_brdf(&s, ray_dir), lambert_in_1);
 			nee_throughput_weight = mul3(throughput_weight, div3(brdf_lambert_1, light_density_1 + brdf_density_1));
@@ -1059,6 +1293,21 @@ uint64_t oracle_render(const oracle_scene_t* scene, const oracle_constants_t* co
 	uint32_t first_frame_index, uint32_t frame_count, uint32_t frame_stride,
 	int accumulate, float* accum, int thread_count)
 {
+	return oracle_render_light_sampling(scene, constants, lights, light_count, 0, strategy, path_length, emission_material_index,
+		first_frame_index, frame_count, frame_stride, accumulate, accum, thread_count);
+}
+
+uint64_t oracle_render_light_sampling(const oracle_scene_t* scene, const oracle_constants_t* constants,
+	const float* lights, uint32_t light_count, int light_sampling,
+	int strategy, uint32_t path_length, uint32_t emission_material_index,
+	uint32_t first_frame_index, uint32_t frame_count, uint32_t frame_stride,
+	int accumulate, float* accum, int thread_count)
+{
+	float* light_nodes = NULL;
+	float* tree_lights = NULL;
+	uint32_t light_leaf_count = 0;
+	if (light_sampling)
+		build_light_tree(lights, light_count, &light_nodes, &tree_lights, &light_leaf_count);
 	if (thread_count < 1) thread_count = 1;
 	if (thread_count > 256) thread_count = 256;
 	render_job_t jobs[256];
@@ -1070,6 +1319,10 @@ uint64_t oracle_render(const oracle_scene_t* scene, const oracle_constants_t* co
 		job->ctx.c = constants;
 		job->ctx.lights = lights;
 		job->ctx.light_count = light_count;
+		job->ctx.light_sampling = light_sampling;
+		job->ctx.light_nodes = light_nodes;
+		job->ctx.tree_lights = tree_lights;
+		job->ctx.light_leaf_count = light_leaf_count;
 		job->ctx.path_length = path_length;
 		job->ctx.emission_material_index = emission_material_index;
 		job->ctx.strategy = strategy;
@@ -1094,6 +1347,8 @@ uint64_t oracle_render(const oracle_scene_t* scene, const oracle_constants_t* co
 	uint64_t rays = 0;
 	for (int i = 0; i != thread_count; ++i)
 		rays += jobs[i].ctx.ray_count;
+	free(light_nodes);
+	free(tree_lights);
 	return rays;
 }
 

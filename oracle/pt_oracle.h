@@ -78,6 +78,19 @@ uint64_t oracle_render(const oracle_scene_t* scene, const oracle_constants_t* co
 	uint32_t first_frame_index, uint32_t frame_count, uint32_t frame_stride,
 	int accumulate, float* accum, int thread_count);
 
+/* oracle_render() with a choice of how next event estimation picks its light:
+ * 0 = the reference's loops over all lights (oracle_render() itself), 1 = a
+ * descent through a binary tree over the lights. The second has no
+ * counterpart in the reference; it restates the definition that the HIP
+ * library documents for its light tree and serves to check that library's
+ * arithmetic and, against mode 0, that the estimate converges to the same
+ * image. */
+uint64_t oracle_render_light_sampling(const oracle_scene_t* scene, const oracle_constants_t* constants,
+	const float* lights, uint32_t light_count, int light_sampling,
+	int strategy, uint32_t path_length, uint32_t emission_material_index,
+	uint32_t first_frame_index, uint32_t frame_count, uint32_t frame_stride,
+	int accumulate, float* accum, int thread_count);
+
 /* Primary-ray closest hits for one frame: triangle index (-1 on miss),
  * barycentrics (weights of vertex 1 and 2) and front flag per pixel. */
 void oracle_primary_hits(const oracle_scene_t* scene, const oracle_constants_t* constants,

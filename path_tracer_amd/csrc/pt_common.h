@@ -217,6 +217,12 @@ struct PtSceneView {
 	const f32x4* lights;
 	uint32_t light_count;
 	uint32_t emission_material_index;
+	// Light tree (pt_light_tree.h): two f32x4 per node, node 1 is the root, the
+	// leaves are nodes light_leaf_count ... 2 * light_leaf_count - 1 and leaf j
+	// holds tree_lights[j]
+	const f32x4* light_nodes;
+	const f32x4* tree_lights;
+	uint32_t light_leaf_count;
 };
 
 // Wavefront buffers. Queues are indexed by slot, path state by path index.
@@ -243,7 +249,11 @@ struct PtWavefront {
 #define PT_MAX_PATH_LENGTH 16
 #define PT_TILE 8
 
-enum { PT_STRATEGY_SPHERICAL = 0, PT_STRATEGY_PSA = 1, PT_STRATEGY_BRDF = 2, PT_STRATEGY_NEE = 3 };
+// The first four are the sampling strategies of the reference
+// (src/main.h:83-94). The fifth is next event estimation whose light is chosen
+// by a descent through the light tree instead of a loop over all lights; it
+// has no counterpart in the reference, which stops at 32 lights.
+enum { PT_STRATEGY_SPHERICAL = 0, PT_STRATEGY_PSA = 1, PT_STRATEGY_BRDF = 2, PT_STRATEGY_NEE = 3, PT_STRATEGY_NEE_TREE = 4 };
 
 // How one batch of paths maps to pixels and frames: path p belongs to frame
 // slot p / paths_per_frame and to the 8x8 pixel tile (p % paths_per_frame) / 64

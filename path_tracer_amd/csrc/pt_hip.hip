@@ -15,6 +15,7 @@
 #include "pt_bvh_build.h"
 #include "pt_trace.h"
 #include "pt_shade.h"
+#include "pt_light_tree.h"
 #include "pt_trace_wave.h"
 
 #ifndef PT_SHORT_BATCH_PATHS
@@ -500,6 +501,10 @@ struct pt_scene {
 	uint8_t* texture_blob;
 	float* srgb_to_linear;
 	f32x4* lights;
+	f32x4* light_nodes;
+	f32x4* tree_lights;
+	uint32_t light_leaf_count;
+	int light_sampling;
 	uint32_t light_count;
 	PtNode* nodes;
 	PtTri* tris;
@@ -580,6 +585,9 @@ static PtSceneView pt_scene_view(const pt_scene* s) {
 	v.srgb_to_linear = s->srgb_to_linear;
 	v.lights = s->lights;
 	v.light_count = s->light_count;
+	v.light_nodes = s->light_nodes;
+	v.tree_lights = s->tree_lights;
+	v.light_leaf_count = s->light_leaf_count;
 	v.emission_material_index = s->emission_material_index;
 	return v;
 }
@@ -848,7 +856,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 	s->material_count = (uint32_t) header->material_count;
 	s->texture_count = texture_count;
 	s->positions = NULL; s->normals_uvs = NULL; s->shade_tris = NULL; s->materials = NULL; s->texture_table = NULL; s->texture_blob = NULL;
-	s->srgb_to_linear = NULL; s->lights = NULL; s->light_count = 0; s->nodes = NULL; s->tris = NULL;
+	s->srgb_to_linear = NULL; s->lights = NULL; s->light_count = 0; s->light_nodes = NULL; s->tree_lights = NULL; s->light_leaf_count = 0; s->light_sampling = PT_LIGHT_SAMPLING_EXACT; s->nodes = NULL; s->tris = NULL;
 	memset(&s->bvh_info, 0, sizeof(s->bvh_info));
 	s->strategy = PT_STRATEGY_NEE;
 	s->path_length = 4;
@@ -976,7 +984,7 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 		hipHostFree(s->snapshot_pool[i]);
 	pt_free_render_targets(s);
 	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->shade_tris); hipFree(s->materials); hipFree(s->texture_table); hipFree(s->texture_blob);
-	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->nodes); hipFree(s->tris);
+	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->light_nodes); hipFree(s->tree_lights); hipFree(s->nodes); hipFree(s->tris);
 	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters); hipFree(s->stack_overflow); hipFree(s->stack_overflow_shadow);
 	if (s->shade_done) hipEventDestroy(s->shade_done);
 	if (s->shadow_done) hipEventDestroy(s->shadow_done);
@@ -992,14 +1000,39 @@ extern "C" int pt_set_lights(pt_scene_t* s, const float* lights, uint32_t count)
 		return 1;
 	PT_CHECK(hipSetDevice(s->device));
 	PT_CHECK(hipStreamSynchronize(s->stream));
+	// The light tree is built on the host: it is small (64 bytes per light)
+	// and changes only here
+	PtLightTree tree;
+	pt_build_light_tree(tree, lights, count);
 	f32x4* fresh = NULL;
-	if (pt_alloc(&fresh, count))
+	f32x4* fresh_nodes = NULL;
+	f32x4* fresh_tree_lights = NULL;
+	if (pt_alloc(&fresh, count) || pt_alloc(&fresh_nodes, tree.nodes.size()) || pt_alloc(&fresh_tree_lights, tree.lights.size())
+		|| (count && hipMemcpy(fresh, lights, sizeof(float) * 4 * count, hipMemcpyHostToDevice) != hipSuccess)
+		|| hipMemcpy(fresh_nodes, tree.nodes.data(), sizeof(f32x4) * tree.nodes.size(), hipMemcpyHostToDevice) != hipSuccess
+		|| hipMemcpy(fresh_tree_lights, tree.lights.data(), sizeof(f32x4) * tree.lights.size(), hipMemcpyHostToDevice) != hipSuccess)
+	{
+		printf("Failed to upload %u lights.\n", count);
+		hipFree(fresh); hipFree(fresh_nodes); hipFree(fresh_tree_lights);
 		return 1;
-	if (count)
-		PT_CHECK(hipMemcpy(fresh, lights, sizeof(float) * 4 * count, hipMemcpyHostToDevice));
-	hipFree(s->lights);
+	}
+	hipFree(s->lights); hipFree(s->light_nodes); hipFree(s->tree_lights);
 	s->lights = fresh;
 	s->light_count = count;
+	s->light_nodes = fresh_nodes;
+	s->tree_lights = fresh_tree_lights;
+	s->light_leaf_count = tree.leaf_count;
+	return 0;
+}
+
+extern "C" int pt_set_light_sampling(pt_scene_t* s, int light_sampling) {
+	if (!s)
+		return 1;
+	if (light_sampling != PT_LIGHT_SAMPLING_EXACT && light_sampling != PT_LIGHT_SAMPLING_TREE) {
+		printf("Unsupported light sampling mode %d.\n", light_sampling);
+		return 1;
+	}
+	s->light_sampling = light_sampling;
 	return 0;
 }
 
@@ -1121,7 +1154,12 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 			case PT_STRATEGY_SPHERICAL: hipLaunchKernelGGL(k_shade<PT_STRATEGY_SPHERICAL>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
 			case PT_STRATEGY_PSA: hipLaunchKernelGGL(k_shade<PT_STRATEGY_PSA>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
 			case PT_STRATEGY_BRDF: hipLaunchKernelGGL(k_shade<PT_STRATEGY_BRDF>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
-			default: hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
+			default:
+				if (s->light_sampling == PT_LIGHT_SAMPLING_TREE && s->light_nodes)
+					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE_TREE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a);
+				else
+					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a);
+				break;
 			}
 		}
 		if (s->strategy == PT_STRATEGY_NEE && k < s->path_length) {

@@ -1,0 +1,126 @@
+// Light tree: next event estimation among thousands of spherical lights
+// without a loop over all of them per path vertex. The reference has no
+// counterpart (it stops at 32 lights, src/main.c:691-694, and loops over them,
+// pathtrace.frag.glsl:120-175); what is kept of it is the light model: a light
+// is sampled uniformly within the cone it subtends (pathtrace.frag.glsl:95-106)
+// and emits nothing when it lies behind the horizon of the shading point
+// (pathtrace.frag.glsl:69-83).
+//
+// Structure: a complete binary tree in heap order (node 1 is the root, node i
+// has the children 2i and 2i + 1, leaf j is node leaf_count + j; leaf_count is
+// the light count rounded up to a power of two, so some leaves stay empty).
+// The lights of a node are split between its children at the median of their
+// centres along the longest axis of the box around those centres, the larger
+// half to the left. A node records the box around the spheres below it as
+// centre and half extents, their summed squared radii ("power") and the
+// squared half diagonal.
+//
+// Estimator: a light is chosen by one descent from the root; at every node a
+// child is taken with probability proportional to its weight
+//   power / max(squared distance to the box centre, squared half diagonal),
+// zero when the whole box lies below the horizon. Light i is thus chosen with
+// a probability P(i) > 0 whenever it can contribute, and a direction w has the
+// density sum over the lights i whose cone contains w of P(i) / (2 pi z_i),
+// where z_i is the light's importance (solid angle / 2 pi). That sum is what
+// multiple importance sampling needs for light and BRDF samples alike; it is
+// found by walking the tree along the ray (stackless, by node index) and, per
+// light hit, once from the root to its leaf for P(i). The estimate stays
+// unbiased; only its variance differs from the loop over all lights.
+#pragma once
+#include "pt_common.h"
+
+#include <algorithm>
+#include <vector>
+
+// Host side: the arrays of PtSceneView::light_nodes and ::tree_lights
+struct PtLightTree {
+	uint32_t leaf_count = 0;
+	std::vector<f32x4> nodes;  // 2 per node, 2 * leaf_count nodes (node 0 unused)
+	std::vector<f32x4> lights; // the light of every leaf; empty leaves are zero
+};
+
+// Places the lights order[begin, end) in a subtree that has
+// slot_count leaf slots, starting at leaf slot first_slot
+static inline void pt_place_lights(PtLightTree& tree, const float* lights, std::vector<uint32_t>& order, size_t begin, size_t end, size_t first_slot, size_t slot_count) {
+	if (begin == end)
+		return;
+	if (slot_count == 1) {
+		const float* l = &lights[4 * (size_t) order[begin]];
+		tree.lights[first_slot] = mk4(l[0], l[1], l[2], l[3]);
+		return;
+	}
+	// Median split along the longest axis of the box around the centres
+	// (the lowest axis wins ties, the lower index equal coordinates)
+	int axis = 0;
+	float longest = -1.0f;
+	for (int a = 0; a != 3; ++a) {
+		float low = lights[4 * (size_t) order[begin] + a], high = low;
+		for (size_t i = begin + 1; i != end; ++i) {
+			low = fminf(low, lights[4 * (size_t) order[i] + a]);
+			high = fmaxf(high, lights[4 * (size_t) order[i] + a]);
+		}
+		if (high - low > longest) {
+			longest = high - low;
+			axis = a;
+		}
+	}
+	std::sort(order.begin() + begin, order.begin() + end, [&](uint32_t lhs, uint32_t rhs) {
+		float l = lights[4 * (size_t) lhs + axis], r = lights[4 * (size_t) rhs + axis];
+		return (l != r) ? (l < r) : (lhs < rhs);
+	});
+	size_t left_count = (end - begin + 1) / 2;
+	pt_place_lights(tree, lights, order, begin, begin + left_count, first_slot, slot_count / 2);
+	pt_place_lights(tree, lights, order, begin + left_count, end, first_slot + slot_count / 2, slot_count / 2);
+}
+
+static inline void pt_build_light_tree(PtLightTree& tree, const float* lights, uint32_t count) {
+	uint32_t leaf_count = 1;
+	while (leaf_count < count)
+		leaf_count *= 2;
+	tree.leaf_count = leaf_count;
+	tree.nodes.assign(4 * (size_t) leaf_count, mk4(0.0f, 0.0f, 0.0f, 0.0f));
+	tree.lights.assign(leaf_count, mk4(0.0f, 0.0f, 0.0f, 0.0f));
+	std::vector<uint32_t> order(count);
+	for (uint32_t i = 0; i != count; ++i)
+		order[i] = i;
+	pt_place_lights(tree, lights, order, 0, count, 0, leaf_count);
+	// Boxes as minimum and maximum first
+	std::vector<float> box_min(3 * 2 * (size_t) leaf_count, 0.0f), box_max(3 * 2 * (size_t) leaf_count, 0.0f), power(2 * (size_t) leaf_count, 0.0f);
+	for (size_t j = 0; j != leaf_count; ++j) {
+		f32x4 l = tree.lights[j];
+		size_t node = (size_t) leaf_count + j;
+		float radius = fabsf(l.w);
+		const float center[3] = { l.x, l.y, l.z };
+		for (int a = 0; a != 3; ++a) {
+			box_min[3 * node + a] = center[a] - radius;
+			box_max[3 * node + a] = center[a] + radius;
+		}
+		power[node] = l.w * l.w;
+	}
+	for (size_t node = leaf_count - 1; node >= 1; --node) {
+		size_t c0 = 2 * node, c1 = 2 * node + 1;
+		// A child without power (surplus leaves, lights of radius zero) does not
+		// widen the box
+		bool use_0 = power[c0] > 0.0f, use_1 = power[c1] > 0.0f;
+		for (int a = 0; a != 3; ++a) {
+			if (use_0 && use_1) {
+				box_min[3 * node + a] = fminf(box_min[3 * c0 + a], box_min[3 * c1 + a]);
+				box_max[3 * node + a] = fmaxf(box_max[3 * c0 + a], box_max[3 * c1 + a]);
+			}
+			else if (use_0 || use_1) {
+				box_min[3 * node + a] = box_min[3 * (use_0 ? c0 : c1) + a];
+				box_max[3 * node + a] = box_max[3 * (use_0 ? c0 : c1) + a];
+			}
+		}
+		power[node] = (use_0 ? power[c0] : 0.0f) + (use_1 ? power[c1] : 0.0f);
+	}
+	for (size_t node = 1; node != 2 * (size_t) leaf_count; ++node) {
+		float center[3], half[3];
+		for (int a = 0; a != 3; ++a) {
+			center[a] = 0.5f * (box_min[3 * node + a] + box_max[3 * node + a]);
+			half[a] = 0.5f * (box_max[3 * node + a] - box_min[3 * node + a]);
+		}
+		tree.nodes[2 * node] = mk4(center[0], center[1], center[2], power[node]);
+		tree.nodes[2 * node + 1] = mk4(half[0], half[1], half[2], (half[0] * half[0] + half[1] * half[1]) + half[2] * half[2]);
+	}
+}

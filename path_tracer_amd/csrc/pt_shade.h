@@ -497,6 +497,189 @@ PT_FN void pt_lights_density_2(const PtSceneView& scene, float total_importance,
 }
 
 
+// ---- Light tree (structure and estimator: pt_light_tree.h) ----
+
+// Weight of a node for the descent from a shading point: zero for an empty
+// node and for one whose box lies below the horizon of the shading point
+PT_FN float pt_light_node_weight(const f32x4* nodes, uint32_t node, v3 shading_pos, v3 normal) {
+	f32x4 center_power = nodes[2 * node], half_radius = nodes[2 * node + 1];
+	if (!(center_power.w > 0.0f))
+		return 0.0f;
+	v3 center_dir = mk3(center_power.x, center_power.y, center_power.z) - shading_pos;
+	// The largest dot(normal, x - shading_pos) over the points x of the box
+	float reach = (fabsf(normal.x) * half_radius.x + fabsf(normal.y) * half_radius.y) + fabsf(normal.z) * half_radius.z;
+	if (dot(normal, center_dir) + reach < 0.0f)
+		return 0.0f;
+	return center_power.w / fmaxf(dot(center_dir, center_dir), half_radius.w);
+}
+
+// Chooses a light by one descent and samples its cone like
+// pt_sample_spherical_light(). out_density receives the chosen light's share
+// of the density of the returned direction (selection probability times cone
+// density); it is zero and the direction is the zero vector if no light was
+// sampled.
+PT_FN v3 pt_sample_lights_tree(const PtSceneView& scene, float* out_density, v3 shading_pos, v3 normal, v2 randoms) {
+	*out_density = 0.0f;
+	uint32_t node = 1;
+	float probability = 1.0f;
+	while (node < scene.light_leaf_count) {
+		float weight_0 = pt_light_node_weight(scene.light_nodes, 2 * node, shading_pos, normal);
+		float weight_1 = pt_light_node_weight(scene.light_nodes, 2 * node + 1, shading_pos, normal);
+		float total = weight_0 + weight_1;
+		if (!(total > 0.0f))
+			return mk3(0.0f, 0.0f, 0.0f);
+		float target = randoms.x * total;
+		bool left = target < weight_0 || !(weight_1 > 0.0f);
+		float weight = left ? weight_0 : weight_1;
+		// The random number is reused as in pathtrace.frag.glsl:137
+		randoms.x = fminf(1.0f, (left ? target : (target - weight_0)) / weight);
+		probability *= weight / total;
+		node = 2 * node + (left ? 0u : 1u);
+	}
+	f32x4 light = scene.tree_lights[node - scene.light_leaf_count];
+	float importance = pt_spherical_light_importance(light, shading_pos, normal);
+	if (!(importance > 0.0f))
+		return mk3(0.0f, 0.0f, 0.0f);
+	*out_density = probability / ((2.0f * PT_PI) * importance);
+	return pt_sample_spherical_light(light, importance, shading_pos, randoms);
+}
+
+// The probability with which the descent of pt_sample_lights_tree() arrives
+// at a given leaf node, by the same arithmetic
+PT_FN float pt_light_tree_probability(const PtSceneView& scene, uint32_t leaf_node, v3 shading_pos, v3 normal) {
+	float probability = 1.0f;
+	for (uint32_t shift = 31u - (uint32_t) __builtin_clz(leaf_node); shift-- != 0;) {
+		uint32_t node = leaf_node >> shift;
+		float weight_0 = pt_light_node_weight(scene.light_nodes, node & ~1u, shading_pos, normal);
+		float weight_1 = pt_light_node_weight(scene.light_nodes, node | 1u, shading_pos, normal);
+		float weight = (node & 1u) ? weight_1 : weight_0;
+		if (!(weight > 0.0f))
+			return 0.0f;
+		probability *= weight / (weight_0 + weight_1);
+	}
+	return probability;
+}
+
+// Reciprocal of a direction for slab tests; components too small to invert
+// are replaced by +-1e-30
+PT_FN v3 pt_safe_reciprocal(v3 dir) {
+	float x = (fabsf(dir.x) > 1.0e-30f) ? dir.x : copysignf(1.0e-30f, dir.x);
+	float y = (fabsf(dir.y) > 1.0e-30f) ? dir.y : copysignf(1.0e-30f, dir.y);
+	float z = (fabsf(dir.z) > 1.0e-30f) ? dir.z : copysignf(1.0e-30f, dir.z);
+	return mk3(1.0f / x, 1.0f / y, 1.0f / z);
+}
+
+// Whether a ray from the origin meets the box [low, high] at a parameter >= 0
+PT_FN bool pt_ray_meets_box(v3 low, v3 high, v3 inv_dir) {
+	float x0 = low.x * inv_dir.x, x1 = high.x * inv_dir.x;
+	float y0 = low.y * inv_dir.y, y1 = high.y * inv_dir.y;
+	float z0 = low.z * inv_dir.z, z1 = high.z * inv_dir.z;
+	float t_near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+	float t_far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+	return t_near <= t_far;
+}
+
+// Lights met by the rays of pt_lights_density_tree_2() whose share of the
+// densities is still to be added: leaf node | ray 0 meets it << 30 | ray 1
+// meets it << 31, in the order of discovery. The shares are added after the
+// walk (or when four have gathered), so that the threads of a wavefront work
+// on them at the same time instead of one after the other in the middle of
+// their walks.
+struct PtLightHits {
+	uint32_t entry_0, entry_1, entry_2, entry_3, count;
+};
+
+PT_FN void pt_light_hit_density(const PtSceneView& scene, uint32_t entry, v3 shading_pos, v3 normal, float& density_0, float& density_1) {
+	uint32_t node = entry & 0x3fffffffu;
+	float importance = pt_spherical_light_importance(scene.tree_lights[node - scene.light_leaf_count], shading_pos, normal);
+	if (importance > 0.0f) {
+		float density = pt_light_tree_probability(scene, node, shading_pos, normal) / ((2.0f * PT_PI) * importance);
+		density_0 += (entry & 0x40000000u) ? density : 0.0f;
+		density_1 += (entry & 0x80000000u) ? density : 0.0f;
+	}
+}
+
+PT_FN void pt_light_hits_flush(const PtSceneView& scene, PtLightHits& hits, v3 shading_pos, v3 normal, float& density_0, float& density_1) {
+	if (hits.count > 0) pt_light_hit_density(scene, hits.entry_0, shading_pos, normal, density_0, density_1);
+	if (hits.count > 1) pt_light_hit_density(scene, hits.entry_1, shading_pos, normal, density_0, density_1);
+	if (hits.count > 2) pt_light_hit_density(scene, hits.entry_2, shading_pos, normal, density_0, density_1);
+	if (hits.count > 3) pt_light_hit_density(scene, hits.entry_3, shading_pos, normal, density_0, density_1);
+	hits.count = 0;
+}
+
+// One node of the walk of pt_lights_density_tree_2(). An inner node: whether
+// one of the two rays meets its box (a slab test, the box widened a little so
+// that rounding skips no light that the test below would accept). A leaf:
+// notes its light in hits if a ray meets it (the test of
+// pathtrace.frag.glsl:160-170) and returns false.
+PT_FN bool pt_light_tree_visit(const PtSceneView& scene, uint32_t node, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, v3 inv_dir_0, v3 inv_dir_1, PtLightHits& hits, float& density_0, float& density_1) {
+	f32x4 center_power = scene.light_nodes[2 * node];
+	if (!(center_power.w > 0.0f))
+		return false;
+	if (node < scene.light_leaf_count) {
+		f32x4 half_radius = scene.light_nodes[2 * node + 1];
+		v3 center_dir = mk3(center_power.x, center_power.y, center_power.z) - shading_pos;
+		v3 reach = mk3(fmaf(half_radius.x, 1.0001f, 4.0e-7f * fabsf(center_dir.x)), fmaf(half_radius.y, 1.0001f, 4.0e-7f * fabsf(center_dir.y)), fmaf(half_radius.z, 1.0001f, 4.0e-7f * fabsf(center_dir.z)));
+		v3 low = center_dir - reach, high = center_dir + reach;
+		return pt_ray_meets_box(low, high, inv_dir_0) || pt_ray_meets_box(low, high, inv_dir_1);
+	}
+	f32x4 light = scene.tree_lights[node - scene.light_leaf_count];
+	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
+	float center_dist_2 = dot(center_dir, center_dir);
+	float in_sphere = center_dist_2 - light.w * light.w;
+	float center_dot_dir_0 = dot(center_dir, dir_0), center_dot_dir_1 = dot(center_dir, dir_1);
+	float discriminant_0 = center_dot_dir_0 * center_dot_dir_0 - in_sphere, discriminant_1 = center_dot_dir_1 * center_dot_dir_1 - in_sphere;
+	bool hit_0 = discriminant_0 >= 0.0f && in_sphere >= 0.0f && center_dot_dir_0 >= 0.0f;
+	bool hit_1 = discriminant_1 >= 0.0f && in_sphere >= 0.0f && center_dot_dir_1 >= 0.0f;
+	if (hit_0 || hit_1) {
+		if (hits.count == 4)
+			pt_light_hits_flush(scene, hits, shading_pos, normal, density_0, density_1);
+		uint32_t entry = node | (hit_0 ? 0x40000000u : 0u) | (hit_1 ? 0x80000000u : 0u);
+		if (hits.count == 0) hits.entry_0 = entry;
+		else if (hits.count == 1) hits.entry_1 = entry;
+		else if (hits.count == 2) hits.entry_2 = entry;
+		else hits.entry_3 = entry;
+		++hits.count;
+	}
+	return false;
+}
+
+// Densities of two directions under pt_sample_lights_tree(): for each, the sum
+// over the lights that a ray along it meets of selection probability times
+// cone density, in leaf order. One depth-first walk serves both rays; a
+// subtree is entered when one of the rays meets its box. Both children of a
+// node are looked at together; a right child still to be entered is remembered
+// as one bit per tree level (the node index itself tells the way back).
+PT_FN void pt_lights_density_tree_2(const PtSceneView& scene, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float* out_density_0, float* out_density_1) {
+	float density_0 = 0.0f, density_1 = 0.0f;
+	v3 inv_dir_0 = pt_safe_reciprocal(dir_0), inv_dir_1 = pt_safe_reciprocal(dir_1);
+	PtLightHits hits;
+	hits.entry_0 = hits.entry_1 = hits.entry_2 = hits.entry_3 = hits.count = 0;
+	uint32_t node = 1, depth = 0, pending = 0;
+	bool inside = pt_light_tree_visit(scene, 1, shading_pos, normal, dir_0, dir_1, inv_dir_0, inv_dir_1, hits, density_0, density_1);
+	while (inside) {
+		bool enter_0 = pt_light_tree_visit(scene, 2 * node, shading_pos, normal, dir_0, dir_1, inv_dir_0, inv_dir_1, hits, density_0, density_1);
+		bool enter_1 = pt_light_tree_visit(scene, 2 * node + 1, shading_pos, normal, dir_0, dir_1, inv_dir_0, inv_dir_1, hits, density_0, density_1);
+		if (enter_0 || enter_1) {
+			pending |= (enter_0 && enter_1) ? (1u << depth) : 0u;
+			node = 2 * node + (enter_0 ? 0u : 1u);
+			++depth;
+		}
+		else if (pending != 0) {
+			// Back to the deepest node whose right child waits, and into that child
+			uint32_t level = 31u - (uint32_t) __builtin_clz(pending);
+			pending &= ~(1u << level);
+			node = 2 * (node >> (depth - level)) + 1;
+			depth = level + 1;
+		}
+		else
+			inside = false;
+	}
+	pt_light_hits_flush(scene, hits, shading_pos, normal, density_0, density_1);
+	*out_density_0 = density_0;
+	*out_density_1 = density_1;
+}
+
 // What shading one path vertex produces (the body of one iteration of the
 // loops at pathtrace.frag.glsl:224-362 after the extension ray has returned)
 struct PtVertexResult {
@@ -524,7 +707,8 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 	r.shadow_factor = 0.0f;
 	// In the NEE estimator emission is weighted by nee_throughput, in the
 	// others by throughput (pathtrace.frag.glsl:231,265,293,323)
-	v3 emission_weight = (strategy == PT_STRATEGY_NEE) ? nee_throughput : throughput;
+	bool next_event_estimation = strategy == PT_STRATEGY_NEE || strategy == PT_STRATEGY_NEE_TREE;
+	v3 emission_weight = next_event_estimation ? nee_throughput : throughput;
 	if (hit_prim == 0xffffffffu) {
 		emitted = emission_weight * mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
 		return r;
@@ -566,14 +750,24 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		// pathtrace.frag.glsl:326-355. Both directions are sampled first (the
 		// light's random numbers are drawn before the BRDF's, as in the
 		// reference) so that one loop over the lights yields both densities.
-		float total_light_importance;
-		v3 light_dir = pt_sample_lights(scene, light_cache, &total_light_importance, s.pos, s.normal, pt_random(sx, sy));
+		float total_light_importance = 0.0f, sampled_light_density = 0.0f;
+		v3 light_dir = (strategy == PT_STRATEGY_NEE_TREE)
+			? pt_sample_lights_tree(scene, &sampled_light_density, s.pos, s.normal, pt_random(sx, sy))
+			: pt_sample_lights(scene, light_cache, &total_light_importance, s.pos, s.normal, pt_random(sx, sy));
 		float lambert_in_0 = dot(s.normal, light_dir);
 		r.next_dir = pt_sample_frostbite_brdf(s, pt_random(sx, sy));
 		float lambert_in_1 = dot(s.normal, r.next_dir);
 		float light_density_0 = 0.0f, light_density_1 = 0.0f;
-		if (lambert_in_0 > 0.0f || lambert_in_1 > 0.0f)
-			pt_lights_density_2(scene, total_light_importance, s.pos, light_dir, r.next_dir, &light_density_0, &light_density_1);
+		if (lambert_in_0 > 0.0f || lambert_in_1 > 0.0f) {
+			if (strategy == PT_STRATEGY_NEE_TREE) {
+				pt_lights_density_tree_2(scene, s.pos, s.normal, light_dir, r.next_dir, &light_density_0, &light_density_1);
+				// Like max(1, count) at pathtrace.frag.glsl:172-173: the sampled
+				// light counts even if rounding lets its own ray miss it
+				light_density_0 = fmaxf(light_density_0, sampled_light_density);
+			}
+			else
+				pt_lights_density_2(scene, total_light_importance, s.pos, light_dir, r.next_dir, &light_density_0, &light_density_1);
+		}
 		if (lambert_in_0 > 0.0f) {
 			float brdf_density_0 = pt_frostbite_brdf_density(s, light_dir);
 			r.shadow = true;

@@ -12,9 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libpt_hip.so")
 
 SAMPLING_STRATEGY_SPHERICAL, SAMPLING_STRATEGY_PSA, SAMPLING_STRATEGY_BRDF, SAMPLING_STRATEGY_NEE = range(4)
+LIGHT_SAMPLING_EXACT, LIGHT_SAMPLING_TREE = range(2)
 
 EXPORTED_SYMBOLS = [
-    "pt_create_scene", "pt_destroy_scene", "pt_set_lights", "pt_set_render_settings", "pt_create_render_targets",
+    "pt_create_scene", "pt_destroy_scene", "pt_set_lights", "pt_set_light_sampling", "pt_set_render_settings", "pt_create_render_targets",
     "pt_render_samples", "pt_synchronize", "pt_read_accumulation", "pt_get_accumulation_device_pointer",
     "pt_set_sample_count", "pt_set_instrumentation", "pt_get_statistics", "pt_reset_statistics", "pt_get_bvh_info",
     "pt_trace_primary_rays", "pt_trace_rays", "pt_evaluate_shading_data", "pt_random_numbers",
@@ -80,6 +81,7 @@ def lib():
         _lib.pt_destroy_scene.argtypes = [vp]
         _lib.pt_destroy_scene.restype = None
         _lib.pt_set_lights.argtypes = [vp, vp, u32]
+        _lib.pt_set_light_sampling.argtypes = [vp, i32]
         _lib.pt_set_render_settings.argtypes = [vp, i32, u32, u32]
         _lib.pt_create_render_targets.argtypes = [vp, u32, u32]
         _lib.pt_render_samples.argtypes = [vp, C.POINTER(Constants), u32, u32, u32, i32]
@@ -152,6 +154,9 @@ class Scene:
     def set_lights(self, lights):
         lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 4)
         _check(lib().pt_set_lights(self.handle, _ptr(lights), len(lights)), "pt_set_lights")
+
+    def set_light_sampling(self, light_sampling):
+        _check(lib().pt_set_light_sampling(self.handle, light_sampling), "pt_set_light_sampling")
 
     def set_render_settings(self, sampling_strategy=SAMPLING_STRATEGY_NEE, path_length=4, emission_material_index=0):
         _check(lib().pt_set_render_settings(self.handle, sampling_strategy, path_length, emission_material_index), "pt_set_render_settings")

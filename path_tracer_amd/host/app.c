@@ -161,6 +161,10 @@ int apply_render_settings(lit_scene_t* lit_scene, const render_settings_t* setti
 	return pt_set_render_settings(lit_scene->scene.device_scene, (int) settings->sampling_strategy, settings->path_length, lit_scene->scene.emission_material_index);
 }
 
+int set_light_sampling(lit_scene_t* lit_scene, int light_sampling) {
+	return pt_set_light_sampling(lit_scene->scene.device_scene, light_sampling);
+}
+
 /* src/main.c:519-560 */
 int create_render_targets(render_targets_t* render_targets, lit_scene_t* lit_scene, uint32_t width, uint32_t height) {
 	memset(render_targets, 0, sizeof(*render_targets));

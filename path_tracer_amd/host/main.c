@@ -10,10 +10,11 @@
 
 static void print_usage(void) {
 	printf("Usage: pt_render [-data ROOT] [-save FILE.rt_save] [-scene N] [-wWIDTH] [-hHEIGHT] [-spp N] [-path_length N]\n"
-		"                 [-strategy spherical|psa|brdf|nee] [-device N] [-o OUT.png|OUT.jpg|OUT.hdr] [-display]\n"
+		"                 [-strategy spherical|psa|brdf|nee] [-device N] [-o OUT.png|OUT.jpg|OUT.hdr] [-display] [-light_tree]\n"
 		"       pt_render -bBEGIN -eEND [-data ROOT] [-out ROOT] [-no_screenshots] [-max_spp N] [-wWIDTH] [-hHEIGHT]\n"
 		"ROOT is the directory holding data/ (default: the working directory, like the reference).\n"
 		"-display saves what the window would show (tonemapper and exposure of the quicksave) instead of a screenshot.\n"
+		"-light_tree lets next event estimation choose its light through a tree over the lights (for thousands of lights).\n"
 		"-bBEGIN -eEND runs slides BEGIN to END-1; screenshots go to renders/ below -out.\n");
 }
 
@@ -22,7 +23,7 @@ int main(int argc, char** argv) {
 	const char* save_path = NULL;
 	const char* out_path = "screenshot.png";
 	const char* output_root = ".";
-	int scene_override = -1, device = 0, display = 0, slide_screenshots = 1;
+	int scene_override = -1, device = 0, display = 0, slide_screenshots = 1, light_tree = 0;
 	uint32_t slide_begin = 0, slide_end = 0, max_spp = 0;
 	uint32_t width = 1280, height = 1024, spp = 64;
 	render_settings_t settings;
@@ -38,6 +39,7 @@ int main(int argc, char** argv) {
 		else if (!strcmp(arg, "-o") && i + 1 < argc) out_path = argv[++i];
 		else if (!strcmp(arg, "-out") && i + 1 < argc) output_root = argv[++i];
 		else if (!strcmp(arg, "-display")) display = 1;
+		else if (!strcmp(arg, "-light_tree")) light_tree = 1;
 		else if (!strcmp(arg, "-no_screenshots")) slide_screenshots = 0;
 		else if (!strcmp(arg, "-max_spp") && i + 1 < argc) max_spp = (uint32_t) atoi(argv[++i]);
 		else if (arg[0] == '-' && arg[1] == 'b' && arg[2]) slide_begin = (uint32_t) atoi(arg + 2);
@@ -87,7 +89,7 @@ int main(int argc, char** argv) {
 	if (create_lit_scene(&lit_scene, device, &spec, data_root))
 		return 1;
 	render_targets_t targets;
-	if (apply_render_settings(&lit_scene, &settings) || create_render_targets(&targets, &lit_scene, width, height)) {
+	if (apply_render_settings(&lit_scene, &settings) || set_light_sampling(&lit_scene, light_tree ? PT_LIGHT_SAMPLING_TREE : PT_LIGHT_SAMPLING_EXACT) || create_render_targets(&targets, &lit_scene, width, height)) {
 		free_lit_scene(&lit_scene);
 		return 1;
 	}

@@ -193,6 +193,9 @@ void free_lit_scene(lit_scene_t* lit_scene);
 /* Applies render_settings_t and the light list to the device scene (what
  * create_scene_subpass() bakes into shader defines at src/main.c:936-949) */
 int apply_render_settings(lit_scene_t* lit_scene, const render_settings_t* settings);
+/* Not in the reference: PT_LIGHT_SAMPLING_EXACT (its loops over all lights,
+ * the default) or PT_LIGHT_SAMPLING_TREE for next event estimation */
+int set_light_sampling(lit_scene_t* lit_scene, int light_sampling);
 /* src/main.c:519-560 */
 int create_render_targets(render_targets_t* render_targets, lit_scene_t* lit_scene, uint32_t width, uint32_t height);
 /* src/main.c:629-676 */

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "get_world_to_view_space", "get_view_to_projection_space", "get_world_to_projection_space",
     "load_scene", "free_scene", "load_textures", "free_textures",
     "get_scene_file", "quicksave", "quickload", "init_scene_spec", "init_render_settings",
-    "create_lit_scene_from_paths", "create_lit_scene", "free_lit_scene", "apply_render_settings",
+    "create_lit_scene_from_paths", "create_lit_scene", "free_lit_scene", "apply_render_settings", "set_light_sampling",
     "create_render_targets", "write_constant_buffer", "render_frames", "save_screenshot", "write_hdr", "write_png",
 ]
 
@@ -125,6 +125,7 @@ def lib():
         _lib.free_lit_scene.argtypes = [C.POINTER(LitScene)]
         _lib.free_lit_scene.restype = None
         _lib.apply_render_settings.argtypes = [C.POINTER(LitScene), C.POINTER(RenderSettings)]
+        _lib.set_light_sampling.argtypes = [C.POINTER(LitScene), C.c_int]
         _lib.create_render_targets.argtypes = [C.POINTER(RenderTargets), C.POINTER(LitScene), u32, u32]
         _lib.write_constant_buffer.argtypes = [C.POINTER(hip_api.Constants), C.POINTER(SceneSpec), C.POINTER(LitScene), C.POINTER(RenderTargets)]
         _lib.render_frames.argtypes = [C.POINTER(SceneSpec), C.POINTER(LitScene), C.POINTER(RenderTargets), u32]
@@ -189,6 +190,9 @@ class Renderer:
     def set_render_settings(self, sampling_strategy, path_length):
         self.settings = RenderSettings(sampling_strategy, path_length)
         _check(lib().apply_render_settings(C.byref(self.lit_scene), C.byref(self.settings)), "apply_render_settings")
+
+    def set_light_sampling(self, light_sampling):
+        _check(lib().set_light_sampling(C.byref(self.lit_scene), light_sampling), "set_light_sampling")
 
     def resize(self, width, height):
         _check(lib().create_render_targets(C.byref(self.targets), C.byref(self.lit_scene), width, height), "create_render_targets")

@@ -8,6 +8,7 @@
 #include "../../path_tracer_amd/csrc/pt_bvh_build.h"
 #include "../../path_tracer_amd/csrc/pt_trace.h"
 #include "../../path_tracer_amd/csrc/pt_shade.h"
+#include "../../path_tracer_amd/csrc/pt_light_tree.h"
 #include <algorithm>
 #include <vector>
 #include <cstdio>
@@ -34,6 +35,7 @@ struct EmuScene {
 	std::vector<uint8_t> blob;
 	std::vector<float> srgb;
 	std::vector<f32x4> lights;
+	PtLightTree light_tree;
 	std::vector<PtNode> nodes;
 	std::vector<PtTri> tris;
 	uint32_t node_count, depth, max_stack;
@@ -45,6 +47,7 @@ struct EmuScene {
 		v.shade_tris = shade_tris.data(); v.materials = materials.data();
 		v.texture_table = texture_table.data(); v.texture_blob = blob.data(); v.srgb_to_linear = srgb.data();
 		v.lights = lights.data(); v.light_count = (uint32_t) lights.size(); v.emission_material_index = emission_material_index;
+		v.light_nodes = light_tree.nodes.data(); v.tree_lights = light_tree.lights.data(); v.light_leaf_count = light_tree.leaf_count;
 		return v;
 	}
 };
@@ -295,6 +298,7 @@ void emu_destroy_scene(EmuScene* s) { delete s; }
 void emu_set_lights(EmuScene* s, const float* lights, uint32_t count) {
 	s->lights.resize(count);
 	if (count) memcpy(s->lights.data(), lights, 16 * (size_t) count);
+	pt_build_light_tree(s->light_tree, lights, count);
 }
 
 void emu_bvh_info(EmuScene* s, uint32_t* out) { out[0] = s->node_count; out[1] = s->depth; out[2] = s->max_stack; }

@@ -67,6 +67,43 @@ def random_lights(seed, count, extent=10.0, radius=(0.1, 0.5)):
     return lights
 
 
+def lit_room(seed=1, light_count=64, extent=12.0, texture_size=16):
+    """A floor, two walls and light_count emissive octahedra floating above the floor, each inscribed in a spherical
+    light (like the tessellated light spheres of the reference's scenes). Returns the scene and its lights."""
+    rng = np.random.default_rng(seed)
+    h = extent / 2
+    quads = [[(-h, -h, 0), (h, -h, 0), (h, h, 0), (-h, h, 0)],
+             [(-h, h, 0), (h, h, 0), (h, h, h), (-h, h, h)],
+             [(-h, -h, 0), (-h, h, 0), (-h, h, h), (-h, -h, h)]]
+    tris = []
+    for q in quads:
+        tris += [[q[0], q[1], q[2]], [q[0], q[2], q[3]]]
+    materials = [1, 1, 2, 2, 1, 1]
+    lights = np.zeros((light_count, 4), np.float32)
+    lights[:, :2] = rng.uniform(-h * 0.9, h * 0.9, (light_count, 2))
+    lights[:, 2] = rng.uniform(1.0, h * 0.8, light_count)
+    lights[:, 3] = rng.uniform(0.08, 0.3, light_count)
+    axes = np.concatenate([np.eye(3), -np.eye(3)])
+    faces = [(0, 1, 2), (1, 3, 2), (3, 4, 2), (4, 0, 2), (1, 0, 5), (3, 1, 5), (4, 3, 5), (0, 4, 5)]
+    for x, y, z, r in lights:
+        corners = np.array([x, y, z]) + 0.999 * r * axes
+        tris += [[corners[a], corners[b], corners[c]] for a, b, c in faces]
+        materials += [0] * 8
+    verts = np.array(tris, np.float64)
+    positions, factor, summand = quantize_positions(verts.reshape(-1, 3))
+    geometric = np.cross(verts[:, 1] - verts[:, 0], verts[:, 2] - verts[:, 0])
+    geometric /= np.maximum(np.linalg.norm(geometric, axis=1, keepdims=True), 1e-12)
+    # normals towards the room and outwards from the octahedra respectively
+    geometric[:6] *= np.sign((geometric[:6] * (np.array([0, 0, 1.0]) - verts[:6].mean(axis=1))).sum(axis=1, keepdims=True))
+    uv = rng.integers(0, 65536, (3 * len(tris), 2)).astype(np.uint16)
+    normals_uvs = np.concatenate([encode_octahedral(np.repeat(geometric, 3, axis=0)), uv], axis=1).astype(np.uint16)
+    textures = []
+    for _ in range(3):
+        textures += [random_texture(rng, texture_size, 132), random_texture(rng, texture_size, 131), random_texture(rng, texture_size, 141)]
+    scene = formats.Scene(["_emission", "floor", "wall"], len(tris), factor, summand, positions, normals_uvs, np.array(materials, np.uint8), textures)
+    return scene, lights
+
+
 def look_at_spec(position, angles, frame_index=100, sky=(0.2, 0.4, 1.0), sky_strength=1.0, emission_strength=10.0, camera_type=0):
     spec = formats.default_scene_spec()
     spec["position"] = position

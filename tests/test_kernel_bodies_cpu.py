@@ -167,3 +167,63 @@ def test_tree_quality_against_sah_yardstick(tmp_path, monkeypatch):
     assert results["lbvh"][2] <= 1.15 * results["sah"][2], (results["lbvh"][2], results["sah"][2])
     assert results["lbvh"][3] <= 8.0  # one triangle per leaf child: few triangle tests per ray
     assert results["lbvh"][4]["node_count"] < scene.triangle_count / 3
+
+
+@pytest.mark.parametrize("light_count", [1, 2, 5, 37, 300])
+def test_render_exact_light_tree(light_count):
+    """Next event estimation through the light tree: the kernel body against the oracle's restatement of the same
+    definition, for light counts that are and are not powers of two (empty leaves) and exceed the reference's 32."""
+    scene = synthetic.triangle_soup(seed=30 + light_count, triangle_count=1500, material_count=3)
+    lights = synthetic.random_lights(40 + light_count, light_count)
+    o_scene, e_scene = oracle.OracleScene(scene), emu.EmuScene(scene)
+    e_scene.set_lights(lights)
+    spec = synthetic.look_at_spec((0.5, 7.0, 0.3), (1.3, 0.0, 0.4))
+    constants = oracle.write_constants(spec, 40, 24, scene, lights)
+    a, rays_a = o_scene.render(constants, lights, strategy=3, path_length=4, first_frame_index=5, frame_count=2, threads=4, light_sampling=1)
+    b, rays_b = e_scene.render(constants, strategy=4, path_length=4, first_frame_index=5, frame_count=2)
+    assert rays_a == rays_b
+    assert ((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all()
+    # The tree changes which light a vertex samples, so the image differs from the loop over all lights
+    c, _ = o_scene.render(constants, lights, strategy=3, path_length=4, first_frame_index=5, frame_count=2, threads=4)
+    if light_count > 1:
+        assert not (bits(a) == bits(c)).all()
+
+
+def test_light_tree_degenerate_lights():
+    """No lights, lights of radius zero and coincident lights neither crash nor yield NaN where the loop does not."""
+    scene = synthetic.triangle_soup(seed=3, triangle_count=500, material_count=2)
+    o_scene, e_scene = oracle.OracleScene(scene), emu.EmuScene(scene)
+    spec = synthetic.look_at_spec((0.5, 7.0, 0.3), (1.3, 0.0, 0.4))
+    for lights in (np.zeros((0, 4), np.float32), np.array([[1, 2, 3, 0]], np.float32), np.array([[1, 2, 3, 0.5]] * 3 + [[4, 4, 4, 0.0]], np.float32)):
+        e_scene.set_lights(lights)
+        constants = oracle.write_constants(spec, 24, 16, scene, lights)
+        a, rays_a = o_scene.render(constants, lights, strategy=3, path_length=3, first_frame_index=1, frame_count=1, light_sampling=1)
+        b, rays_b = e_scene.render(constants, strategy=4, path_length=3, first_frame_index=1, frame_count=1)
+        assert rays_a == rays_b
+        assert ((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all()
+        assert np.isfinite(a).all()
+
+
+def test_light_tree_converges_to_the_loop_over_all_lights():
+    """Unbiasedness: direct light on a floor below 100 emitters, many samples. The tree estimate, the reference's
+    loop over all lights and BRDF sampling (which involves no light list at all) agree in the image mean and per
+    pixel within their noise; a tree that dropped or double-counted lights, or whose density did not match its
+    sampling, would not. The camera sees the floor only: on an emitter's surface a shading point lies inside the
+    light's sphere, where the reference's sampling is degenerate and its estimate differs from BRDF sampling."""
+    scene, lights = synthetic.lit_room(seed=8, light_count=100)
+    o_scene = oracle.OracleScene(scene)
+    spec = synthetic.look_at_spec((3.0, -4.0, 0.6), (0.6, 0.0, 2.5), sky_strength=0.0)
+    constants = oracle.write_constants(spec, 24, 16, scene, lights)
+    assert (o_scene.primary_hits(constants, 1)[0] == 0).all()
+    spp = 1024
+    images = {}
+    for i, (name, strategy, light_sampling) in enumerate([("loop", 3, 0), ("tree", 3, 1), ("loop again", 3, 0), ("brdf", 2, 0)]):
+        accum, _ = o_scene.render(constants, lights, strategy=strategy, path_length=2, first_frame_index=1 + i * spp, frame_count=spp, threads=8, light_sampling=light_sampling)
+        images[name] = accum[..., :3] / spp
+    mean = images["loop"].mean()
+    assert mean > 0.05
+    relative = {name: abs(image.mean() - mean) / mean for name, image in images.items()}
+    rmse = {name: np.sqrt(((image - images["loop"]) ** 2).mean()) / mean for name, image in images.items()}
+    print("relative differences of image means", relative, "relative RMSE", rmse)
+    assert relative["tree"] < 0.015 and relative["loop again"] < 0.015 and relative["brdf"] < 0.05
+    assert rmse["tree"] < 2.0 * rmse["loop again"] + 0.02

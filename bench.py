@@ -12,6 +12,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -60,6 +62,10 @@ def parse_args():
     p.add_argument("--workload", choices=sorted(WORKLOADS), default="cornell",
                    help="cornell: the reference's own scene file; city / interior: generated stand-ins for Bistro exterior / Arcade")
     p.add_argument("--triangles", type=int, default=None, help="triangle budget of a generated workload")
+    p.add_argument("--lights", type=int, default=None,
+                   help="replace the workload's lights by this many spheres placed uniformly in the scene's bounding box (seed 4, radius 0.1 to 0.5)")
+    p.add_argument("--light-sampling", choices=("loop", "tree"), default="loop",
+                   help="loop: the reference's loops over all lights per vertex; tree: one descent through the light tree")
     p.add_argument("--scene-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "pt_scenes"))
     return p.parse_args()
 
@@ -84,6 +90,17 @@ def measured_hbm_traffic(workload, kernel):
     return entry["hbm_bytes_per_launch"] if entry else None
 
 
+def generated_lights(count, factor, summand):
+    """count lights uniform in the bounding box of the quantised positions (21 bits per axis)."""
+    rng = np.random.default_rng(4)
+    low = np.asarray(summand, np.float64)
+    high = low + np.asarray(factor, np.float64) * float((1 << 21) - 1)
+    lights = np.zeros((count, 4), np.float32)
+    lights[:, :3] = rng.uniform(low, high, (count, 3))
+    lights[:, 3] = rng.uniform(0.1, 0.5, count)
+    return lights
+
+
 def cpu_baseline(args, threads, root, first_frame_index):
     """The CPU oracle on a bounded sample of the same workload (reported baseline, not the target)."""
     import oracle
@@ -93,12 +110,15 @@ def cpu_baseline(args, threads, root, first_frame_index):
     scene = formats.load_scene(os.path.join(data, name + ".vks"), os.path.join(data, textures))
     lights = formats.load_lights(os.path.join(data, name + ".lights"))
     spec = formats.load_rt_save(os.path.join(data, "saves", save))
+    if args.lights is not None:
+        lights = generated_lights(args.lights, scene.dequantization_factor, scene.dequantization_summand)
     # About 10-30 s of CPU work: one step of the Cornell workload, a quarter of one for the larger scenes
     width, height, spp = args.width, args.height, (32 if args.workload == "cornell" else 8)
     constants = oracle.write_constants(spec, width, height, scene, lights)
     cpu_scene = oracle.OracleScene(scene)
     begin = time.perf_counter()
-    _, rays = cpu_scene.render(constants, lights, strategy=3, path_length=args.path_length, first_frame_index=first_frame_index, frame_count=spp, threads=threads)
+    _, rays = cpu_scene.render(constants, lights, strategy=3, path_length=args.path_length, first_frame_index=first_frame_index, frame_count=spp, threads=threads,
+                               light_sampling=int(args.light_sampling == "tree"))
     seconds = time.perf_counter() - begin
     return {"value": rays / seconds * 1e-6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": "CPU oracle, %s %dx%d, %d spp, NEE, path length %d, %d rays in %.2f s" % (label, width, height, spp, args.path_length, rays, seconds)}
@@ -133,6 +153,14 @@ def main():
     constants = renderer.constants()
     lib = hip_api.lib()
     import ctypes as C
+    light_count = renderer.lit_scene.spherical_light_count
+    if args.lights is not None:
+        header = renderer.lit_scene.scene.header
+        lights = generated_lights(args.lights, list(header.dequantization_factor), list(header.dequantization_summand))
+        if lib.pt_set_lights(renderer.device_scene, lights.ctypes.data_as(C.c_void_p), len(lights)):
+            raise RuntimeError("pt_set_lights failed")
+        light_count = len(lights)
+    renderer.set_light_sampling(hip_api.LIGHT_SAMPLING_TREE if args.light_sampling == "tree" else hip_api.LIGHT_SAMPLING_EXACT)
 
     spp = args.spp_per_step
     next_frame = [spec.frame_index + 1]
@@ -208,6 +236,7 @@ def main():
             "data": ("Cornell box scene file of the reference (fixture copy of data/cornell_box.vks, its textures, lights and quicksave)" if args.workload == "cornell"
                      else "synthetic: scene generated by path_tracer_amd/tools/procedural.py in the reference's file formats"),
             "config": {"workload": "%s %dx%d, NEE + MIS, path length %d, %d spp per step per GPU, frames %d.." % (label, args.width, args.height, args.path_length, spp, spec.frame_index + 1),
+                       "lights": int(light_count), "light_sampling": args.light_sampling,
                        "spp_total": args.steps * spp * world_size, "parallelism": "sample slices x%d + all-reduce" % world_size},
             "samples_per_s": total_paths / seconds,
             "rays_per_path": total_rays / total_paths,

@@ -1047,18 +1047,22 @@ static void accumulate_tree_density(const context_t* ctx, uint32_t node, vec3 sh
 		}
 		return;
 	}
-	/* Skip the subtree unless the ray meets its box (slab test), widened a
-	   little against rounding */
+	/* Skip the subtree unless the ray meets its box: slab test in the form
+	   centre / d - origin / d -+ half / |d| per axis, the box widened by a
+	   ten-thousandth and by a millionth of the coordinates involved (root box
+	   and shading position) against rounding */
+	const float* root = &ctx->light_nodes[8];
+	float slack = 1.0e-6f * ((((fabsf(shading_pos.x) + fabsf(shading_pos.y)) + fabsf(shading_pos.z))
+		+ ((fabsf(root[0]) + fabsf(root[1])) + fabsf(root[2]))) + ((root[4] + root[5]) + root[6]));
 	float t_near = 0.0f, t_far = INFINITY;
 	const float p[3] = { shading_pos.x, shading_pos.y, shading_pos.z }, d[3] = { dir.x, dir.y, dir.z };
 	for (int a = 0; a != 3; ++a) {
 		float safe = (fabsf(d[a]) > 1.0e-30f) ? d[a] : copysignf(1.0e-30f, d[a]);
 		float inv = 1.0f / safe;
-		float offset = n[a] - p[a];
-		float reach = fmaf(n[4 + a], 1.0001f, 4.0e-7f * fabsf(offset));
-		float t0 = (offset - reach) * inv, t1 = (offset + reach) * inv;
-		t_near = fmaxf(t_near, fminf(t0, t1));
-		t_far = fminf(t_far, fmaxf(t0, t1));
+		float t_center = fmaf(n[a], inv, -(p[a] * inv));
+		float t_half = fmaf(n[4 + a], 1.0001f, slack) * fabsf(inv);
+		t_near = fmaxf(t_near, t_center - t_half);
+		t_far = fminf(t_far, t_center + t_half);
 	}
 	if (t_near <= t_far) {
 		accumulate_tree_density(ctx, 2 * node, shading_pos, normal, dir, density);

@@ -560,69 +560,47 @@ PT_FN float pt_light_tree_probability(const PtSceneView& scene, uint32_t leaf_no
 	return probability;
 }
 
-// Reciprocal of a direction for slab tests; components too small to invert
-// are replaced by +-1e-30
-PT_FN v3 pt_safe_reciprocal(v3 dir) {
+// A ray prepared for slab tests against boxes given by centre and half
+// extents: with inv = 1 / direction (components too small to invert replaced
+// by +-1e-30), the ray is inside the slab of an axis for parameters
+// centre * inv - origin * inv -+ half * |inv|
+struct PtSlabRay {
+	v3 inv, origin_inv, abs_inv;
+};
+
+PT_FN PtSlabRay pt_slab_ray(v3 origin, v3 dir) {
 	float x = (fabsf(dir.x) > 1.0e-30f) ? dir.x : copysignf(1.0e-30f, dir.x);
 	float y = (fabsf(dir.y) > 1.0e-30f) ? dir.y : copysignf(1.0e-30f, dir.y);
 	float z = (fabsf(dir.z) > 1.0e-30f) ? dir.z : copysignf(1.0e-30f, dir.z);
-	return mk3(1.0f / x, 1.0f / y, 1.0f / z);
+	PtSlabRay ray;
+	ray.inv = mk3(1.0f / x, 1.0f / y, 1.0f / z);
+	ray.origin_inv = mk3(origin.x * ray.inv.x, origin.y * ray.inv.y, origin.z * ray.inv.z);
+	ray.abs_inv = mk3(fabsf(ray.inv.x), fabsf(ray.inv.y), fabsf(ray.inv.z));
+	return ray;
 }
 
-// Whether a ray from the origin meets the box [low, high] at a parameter >= 0
-PT_FN bool pt_ray_meets_box(v3 low, v3 high, v3 inv_dir) {
-	float x0 = low.x * inv_dir.x, x1 = high.x * inv_dir.x;
-	float y0 = low.y * inv_dir.y, y1 = high.y * inv_dir.y;
-	float z0 = low.z * inv_dir.z, z1 = high.z * inv_dir.z;
-	float t_near = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
-	float t_far = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
+// Whether the ray meets the box at a parameter >= 0
+PT_FN bool pt_ray_meets_box(const PtSlabRay& ray, v3 center, v3 half) {
+	float cx = fmaf(center.x, ray.inv.x, -ray.origin_inv.x), hx = half.x * ray.abs_inv.x;
+	float cy = fmaf(center.y, ray.inv.y, -ray.origin_inv.y), hy = half.y * ray.abs_inv.y;
+	float cz = fmaf(center.z, ray.inv.z, -ray.origin_inv.z), hz = half.z * ray.abs_inv.z;
+	float t_near = fmaxf(fmaxf(cx - hx, cy - hy), fmaxf(cz - hz, 0.0f));
+	float t_far = fminf(fminf(cx + hx, cy + hy), cz + hz);
 	return t_near <= t_far;
 }
 
-// Lights met by the rays of pt_lights_density_tree_2() whose share of the
-// densities is still to be added: leaf node | ray 0 meets it << 30 | ray 1
-// meets it << 31, in the order of discovery. The shares are added after the
-// walk (or when four have gathered), so that the threads of a wavefront work
-// on them at the same time instead of one after the other in the middle of
-// their walks.
-struct PtLightHits {
-	uint32_t entry_0, entry_1, entry_2, entry_3, count;
+// Leaves whose boxes the rays of pt_lights_density_tree_2() meet and whose
+// lights are still to be tested, in the order of discovery. They are worked
+// off after the walk (or when four have gathered), so that the threads of a
+// wavefront do the sphere tests and the 14-level probability loops at the same
+// time instead of one after the other in the middle of their walks.
+struct PtLightLeaves {
+	uint32_t node_0, node_1, node_2, node_3, count;
 };
 
-PT_FN void pt_light_hit_density(const PtSceneView& scene, uint32_t entry, v3 shading_pos, v3 normal, float& density_0, float& density_1) {
-	uint32_t node = entry & 0x3fffffffu;
-	float importance = pt_spherical_light_importance(scene.tree_lights[node - scene.light_leaf_count], shading_pos, normal);
-	if (importance > 0.0f) {
-		float density = pt_light_tree_probability(scene, node, shading_pos, normal) / ((2.0f * PT_PI) * importance);
-		density_0 += (entry & 0x40000000u) ? density : 0.0f;
-		density_1 += (entry & 0x80000000u) ? density : 0.0f;
-	}
-}
-
-PT_FN void pt_light_hits_flush(const PtSceneView& scene, PtLightHits& hits, v3 shading_pos, v3 normal, float& density_0, float& density_1) {
-	if (hits.count > 0) pt_light_hit_density(scene, hits.entry_0, shading_pos, normal, density_0, density_1);
-	if (hits.count > 1) pt_light_hit_density(scene, hits.entry_1, shading_pos, normal, density_0, density_1);
-	if (hits.count > 2) pt_light_hit_density(scene, hits.entry_2, shading_pos, normal, density_0, density_1);
-	if (hits.count > 3) pt_light_hit_density(scene, hits.entry_3, shading_pos, normal, density_0, density_1);
-	hits.count = 0;
-}
-
-// One node of the walk of pt_lights_density_tree_2(). An inner node: whether
-// one of the two rays meets its box (a slab test, the box widened a little so
-// that rounding skips no light that the test below would accept). A leaf:
-// notes its light in hits if a ray meets it (the test of
-// pathtrace.frag.glsl:160-170) and returns false.
-PT_FN bool pt_light_tree_visit(const PtSceneView& scene, uint32_t node, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, v3 inv_dir_0, v3 inv_dir_1, PtLightHits& hits, float& density_0, float& density_1) {
-	f32x4 center_power = scene.light_nodes[2 * node];
-	if (!(center_power.w > 0.0f))
-		return false;
-	if (node < scene.light_leaf_count) {
-		f32x4 half_radius = scene.light_nodes[2 * node + 1];
-		v3 center_dir = mk3(center_power.x, center_power.y, center_power.z) - shading_pos;
-		v3 reach = mk3(fmaf(half_radius.x, 1.0001f, 4.0e-7f * fabsf(center_dir.x)), fmaf(half_radius.y, 1.0001f, 4.0e-7f * fabsf(center_dir.y)), fmaf(half_radius.z, 1.0001f, 4.0e-7f * fabsf(center_dir.z)));
-		v3 low = center_dir - reach, high = center_dir + reach;
-		return pt_ray_meets_box(low, high, inv_dir_0) || pt_ray_meets_box(low, high, inv_dir_1);
-	}
+// Adds the share of a leaf's light to the densities of the rays that meet the
+// light (the test of pathtrace.frag.glsl:160-170)
+PT_FN void pt_light_leaf_density(const PtSceneView& scene, uint32_t node, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float& density_0, float& density_1) {
 	f32x4 light = scene.tree_lights[node - scene.light_leaf_count];
 	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
 	float center_dist_2 = dot(center_dir, center_dir);
@@ -632,16 +610,32 @@ PT_FN bool pt_light_tree_visit(const PtSceneView& scene, uint32_t node, v3 shadi
 	bool hit_0 = discriminant_0 >= 0.0f && in_sphere >= 0.0f && center_dot_dir_0 >= 0.0f;
 	bool hit_1 = discriminant_1 >= 0.0f && in_sphere >= 0.0f && center_dot_dir_1 >= 0.0f;
 	if (hit_0 || hit_1) {
-		if (hits.count == 4)
-			pt_light_hits_flush(scene, hits, shading_pos, normal, density_0, density_1);
-		uint32_t entry = node | (hit_0 ? 0x40000000u : 0u) | (hit_1 ? 0x80000000u : 0u);
-		if (hits.count == 0) hits.entry_0 = entry;
-		else if (hits.count == 1) hits.entry_1 = entry;
-		else if (hits.count == 2) hits.entry_2 = entry;
-		else hits.entry_3 = entry;
-		++hits.count;
+		float importance = pt_spherical_light_importance(light, shading_pos, normal);
+		if (importance > 0.0f) {
+			float density = pt_light_tree_probability(scene, node, shading_pos, normal) / ((2.0f * PT_PI) * importance);
+			density_0 += hit_0 ? density : 0.0f;
+			density_1 += hit_1 ? density : 0.0f;
+		}
 	}
-	return false;
+}
+
+PT_FN void pt_light_leaves_flush(const PtSceneView& scene, PtLightLeaves& leaves, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float& density_0, float& density_1) {
+	if (leaves.count > 0) pt_light_leaf_density(scene, leaves.node_0, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+	if (leaves.count > 1) pt_light_leaf_density(scene, leaves.node_1, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+	if (leaves.count > 2) pt_light_leaf_density(scene, leaves.node_2, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+	if (leaves.count > 3) pt_light_leaf_density(scene, leaves.node_3, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+	leaves.count = 0;
+}
+
+// Whether one of the two rays meets the box of a node that is not empty (a
+// slab test; the box is widened by a ten-thousandth and by slack, a millionth
+// of the coordinates involved, so that rounding skips no light that the test
+// above would accept)
+PT_FN bool pt_light_tree_visit(const PtSceneView& scene, uint32_t node, const PtSlabRay& ray_0, const PtSlabRay& ray_1, float slack) {
+	f32x4 center_power = scene.light_nodes[2 * node], half_radius = scene.light_nodes[2 * node + 1];
+	v3 center = mk3(center_power.x, center_power.y, center_power.z);
+	v3 half = mk3(fmaf(half_radius.x, 1.0001f, slack), fmaf(half_radius.y, 1.0001f, slack), fmaf(half_radius.z, 1.0001f, slack));
+	return center_power.w > 0.0f && (pt_ray_meets_box(ray_0, center, half) || pt_ray_meets_box(ray_1, center, half));
 }
 
 // Densities of two directions under pt_sample_lights_tree(): for each, the sum
@@ -652,14 +646,39 @@ PT_FN bool pt_light_tree_visit(const PtSceneView& scene, uint32_t node, v3 shadi
 // as one bit per tree level (the node index itself tells the way back).
 PT_FN void pt_lights_density_tree_2(const PtSceneView& scene, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float* out_density_0, float* out_density_1) {
 	float density_0 = 0.0f, density_1 = 0.0f;
-	v3 inv_dir_0 = pt_safe_reciprocal(dir_0), inv_dir_1 = pt_safe_reciprocal(dir_1);
-	PtLightHits hits;
-	hits.entry_0 = hits.entry_1 = hits.entry_2 = hits.entry_3 = hits.count = 0;
+	PtSlabRay ray_0 = pt_slab_ray(shading_pos, dir_0), ray_1 = pt_slab_ray(shading_pos, dir_1);
+	f32x4 root_center = scene.light_nodes[2], root_half = scene.light_nodes[3];
+	float slack = 1.0e-6f * ((((fabsf(shading_pos.x) + fabsf(shading_pos.y)) + fabsf(shading_pos.z))
+		+ ((fabsf(root_center.x) + fabsf(root_center.y)) + fabsf(root_center.z))) + ((root_half.x + root_half.y) + root_half.z));
+	PtLightLeaves leaves;
+	leaves.node_0 = leaves.node_1 = leaves.node_2 = leaves.node_3 = leaves.count = 0;
 	uint32_t node = 1, depth = 0, pending = 0;
-	bool inside = pt_light_tree_visit(scene, 1, shading_pos, normal, dir_0, dir_1, inv_dir_0, inv_dir_1, hits, density_0, density_1);
+	bool inside = pt_light_tree_visit(scene, 1, ray_0, ray_1, slack);
+	if (inside && scene.light_leaf_count == 1) {
+		// A tree of one light: the root is the leaf
+		leaves.node_0 = 1;
+		leaves.count = 1;
+		inside = false;
+	}
 	while (inside) {
-		bool enter_0 = pt_light_tree_visit(scene, 2 * node, shading_pos, normal, dir_0, dir_1, inv_dir_0, inv_dir_1, hits, density_0, density_1);
-		bool enter_1 = pt_light_tree_visit(scene, 2 * node + 1, shading_pos, normal, dir_0, dir_1, inv_dir_0, inv_dir_1, hits, density_0, density_1);
+		bool enter_0 = pt_light_tree_visit(scene, 2 * node, ray_0, ray_1, slack);
+		bool enter_1 = pt_light_tree_visit(scene, 2 * node + 1, ray_0, ray_1, slack);
+		if (2 * node >= scene.light_leaf_count) {
+			// The children are leaves: note those met, left before right
+			for (uint32_t child = 0; child != 2; ++child) {
+				if (child ? enter_1 : enter_0) {
+					if (leaves.count == 4)
+						pt_light_leaves_flush(scene, leaves, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+					uint32_t leaf = 2 * node + child;
+					if (leaves.count == 0) leaves.node_0 = leaf;
+					else if (leaves.count == 1) leaves.node_1 = leaf;
+					else if (leaves.count == 2) leaves.node_2 = leaf;
+					else leaves.node_3 = leaf;
+					++leaves.count;
+				}
+			}
+			enter_0 = enter_1 = false;
+		}
 		if (enter_0 || enter_1) {
 			pending |= (enter_0 && enter_1) ? (1u << depth) : 0u;
 			node = 2 * node + (enter_0 ? 0u : 1u);
@@ -675,7 +694,7 @@ PT_FN void pt_lights_density_tree_2(const PtSceneView& scene, v3 shading_pos, v3
 		else
 			inside = false;
 	}
-	pt_light_hits_flush(scene, hits, shading_pos, normal, density_0, density_1);
+	pt_light_leaves_flush(scene, leaves, shading_pos, normal, dir_0, dir_1, density_0, density_1);
 	*out_density_0 = density_0;
 	*out_density_1 = density_1;
 }

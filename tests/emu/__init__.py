@@ -15,7 +15,7 @@ _CSRC = os.path.join(_HERE, "..", "..", "path_tracer_amd", "csrc")
 
 
 def build(force=False):
-    sources = [os.path.join(_HERE, "pt_emu.cpp")] + [os.path.join(_CSRC, n) for n in ("pt_common.h", "pt_bvh_build.h", "pt_trace.h", "pt_shade.h")]
+    sources = [os.path.join(_HERE, "pt_emu.cpp")] + [os.path.join(_CSRC, n) for n in ("pt_common.h", "pt_bvh_build.h", "pt_trace.h", "pt_shade.h", "pt_light_tree.h")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in sources):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
                                "-o", _LIB, os.path.join(_HERE, "pt_emu.cpp")])

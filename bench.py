@@ -71,7 +71,8 @@ def parse_args():
 
 
 def trace_bytes_per_ray(kind, nodes_per_ray, tris_per_ray, node_bytes, tri_bytes):
-    """Algorithmic bytes one traversal kernel moves per ray (DESIGN.md, section 'Kernels')."""
+    """Algorithmic bytes one traversal kernel moves per ray: its ray and result records plus every node and
+    triangle the ray visits at full size, whether the fetch is served by LDS, a cache or HBM."""
     if kind == "extension":
         stream = 32 + 16  # ray record read, hit record written
     else:

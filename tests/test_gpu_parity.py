@@ -352,3 +352,31 @@ def test_convergence_against_higher_sample_count_oracle(gpu_cornell, oracle_corn
         errors[spp] = float(np.sqrt(((mean - reference) ** 2).mean()) / reference.mean())
     assert errors[64] < 0.3, errors  # a small light: 0.21 measured, the oracle image itself has about 0.05
     assert 1.5 < errors[16] / errors[64] < 2.6, errors
+
+
+def test_command_line_driver(tmp_path):
+    """pt_render, the headless counterpart of the reference's executable: the same pixels as the library calls it makes,
+    a usage message for unknown options, and the light tree switch."""
+    import subprocess
+    from PIL import Image
+    binary = os.path.join(os.path.dirname(host_api.LIB_PATH), "pt_render")
+    assert os.path.exists(binary), "build the host first (make -C path_tracer_amd/host)"
+    png = str(tmp_path / "cli.png")
+    common = [binary, "-data", DATA_ROOT, "-w64", "-h48", "-spp", "16"]
+    done = subprocess.run(common + ["-o", png], capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stdout + done.stderr
+    assert "Mrays/s" in done.stdout and "Saved" in done.stdout
+    spec = host_api.quickload(os.path.join(DATA, "saves", "cornell_box", "default.rt_save"))
+    renderer = host_api.Renderer(spec, DATA_ROOT, device=0, width=64, height=48)
+    renderer.render_frames(16)
+    expected = str(tmp_path / "api.png")
+    renderer.save_screenshot(expected)
+    assert (np.asarray(Image.open(png)) == np.asarray(Image.open(expected))).all()
+    # One light: the tree samples it with probability one, the same image up to the order of operations
+    tree = str(tmp_path / "tree.png")
+    done = subprocess.run(common + ["-light_tree", "-o", tree], capture_output=True, text=True, timeout=120)
+    assert done.returncode == 0, done.stdout + done.stderr
+    assert np.abs(np.asarray(Image.open(tree)).astype(int) - np.asarray(Image.open(png)).astype(int)).max() <= 1
+    done = subprocess.run([binary, "-no_such_option"], capture_output=True, text=True, timeout=60)
+    assert done.returncode != 0 and "Usage" in done.stdout
+    renderer.close()

@@ -205,8 +205,9 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtCons
 		pt_primary_ray(*constants, x, y, batch.first_frame_index + frame_slot * batch.frame_stride, sx, sy, &origin, &dir);
 	wf.ray_o[0][p] = mk4(origin.x, origin.y, origin.z, pt_as_float(inside ? p : PT_INVALID));
 	wf.ray_d[0][p] = mk4(dir.x, dir.y, dir.z, 0.0f);
-	wf.state0[p] = mk4(1.0f, 1.0f, 1.0f, pt_as_float(sx));
-	wf.state1[p] = mk4(1.0f, 1.0f, 1.0f, pt_as_float(sy));
+	// The path state (throughput weights of one, the seed) is not written here:
+	// shading the first vertex derives it from the path index again, which is
+	// cheaper than 32 bytes written and 32 read per path
 	wf.radiance[p] = mk4(0.0f, 0.0f, 0.0f, 0.0f);
 	// ray_count is path_count, or 0 when the path length is 0 and no ray is ever traced
 	if (p == 0)
@@ -310,6 +311,7 @@ __device__ __forceinline__ void pt_stage_srgb_table(const float* table) {
 struct PtShadeArgs {
 	PtSceneView scene;
 	PtWavefront wf;
+	PtBatch batch;
 	const PtConstants* constants;
 	int strategy;
 	uint32_t path_length;
@@ -348,9 +350,21 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(PtShadeArgs a) {
 	}
 	if (active) {
 		f32x4 d = a.wf.ray_d[a.parity][slot];
-		f32x4 s0 = a.wf.state0[path], s1 = a.wf.state1[path];
-		v3 throughput = mk3(s0.x, s0.y, s0.z), nee_throughput = mk3(s1.x, s1.y, s1.z), emitted = mk3(0.0f, 0.0f, 0.0f);
-		uint32_t sx = pt_as_uint(s0.w), sy = pt_as_uint(s1.w);
+		v3 throughput = mk3(1.0f, 1.0f, 1.0f), nee_throughput = mk3(1.0f, 1.0f, 1.0f), emitted = mk3(0.0f, 0.0f, 0.0f);
+		uint32_t sx, sy;
+		if (a.k == 1) {
+			// The state of a path at its first vertex follows from its index
+			uint32_t x, y, frame_slot;
+			pt_path_to_pixel(a.batch, path, &x, &y, &frame_slot);
+			pt_seed_after_primary_ray(x, y, a.batch.first_frame_index + frame_slot * a.batch.frame_stride, sx, sy);
+		}
+		else {
+			f32x4 s0 = a.wf.state0[path], s1 = a.wf.state1[path];
+			throughput = mk3(s0.x, s0.y, s0.z);
+			nee_throughput = mk3(s1.x, s1.y, s1.z);
+			sx = pt_as_uint(s0.w);
+			sy = pt_as_uint(s1.w);
+		}
 		bool missed = hit.x == PT_INVALID;
 		if (a.visit_counters && !missed)
 			atomicAdd(&a.visit_counters[4], 1ull);
@@ -1144,6 +1158,7 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 			PtShadeArgs a;
 			a.scene = pt_scene_view(s);
 			a.wf = s->wf;
+			a.batch = batch;
 			a.constants = s->constants;
 			a.strategy = s->strategy;
 			a.path_length = s->path_length;

@@ -90,6 +90,14 @@ PT_FN v3 pt_camera_ray_direction(v2 tc, const float* m) {
 }
 
 // ---- pathtrace.frag.glsl:365-386: seed, Gaussian pixel jitter, camera ray ----
+// The seed of a path once its primary ray has been generated: the initial
+// seed of pathtrace.frag.glsl:368 advanced by the one draw of pt_primary_ray()
+PT_FN void pt_seed_after_primary_ray(uint32_t x, uint32_t y, uint32_t frame_index, uint32_t& sx, uint32_t& sy) {
+	sx = x ^ (frame_index << 16);
+	sy = y ^ ((frame_index + 237u) << 16);
+	pt_random(sx, sy);
+}
+
 PT_FN void pt_primary_ray(const PtConstants& c, uint32_t x, uint32_t y, uint32_t frame_index, uint32_t& sx, uint32_t& sy, v3* origin, v3* dir) {
 	sx = x ^ (frame_index << 16);
 	sy = y ^ ((frame_index + 237u) << 16);

@@ -35,10 +35,20 @@ static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device con
 
 #define PT_BLOCK 256
 #ifndef PT_LIGHT_CACHE_SIZE
-#define PT_LIGHT_CACHE_SIZE 32 // lights whose importance a shading thread keeps in LDS (32 KB per workgroup)
+// Lights whose importance a shading thread keeps in LDS between the loops of
+// pt_sample_lights(), at most: five workgroups with that many fit the 160 KB of a CU
+#define PT_LIGHT_CACHE_SIZE 28
 #endif
 #ifndef PT_SHADE_BLOCK
-#define PT_SHADE_BLOCK 512 // threads per workgroup of the shading kernel: one queue atomic per workgroup (64: 16 ms, 128: 8.7, 256: 6.1, 512: 5.9 ms per Cornell step)
+// Threads per workgroup of the shading kernel. Every workgroup costs one
+// atomic per queue (64 threads: 16 ms per Cornell step, 128: 8.7, 256: 6.1,
+// 512: 5.9), but the kernel needs just under 96 registers, which allows five
+// waves per SIMD, and only workgroups of four waves (one per SIMD) stack up
+// to five: with 512 threads four waves per SIMD fit, with 640 (ten waves,
+// unevenly spread over the SIMDs) a second workgroup no longer does. Five
+// waves are worth more than the atomics saved (Cornell 5.7 instead of 5.9 ms,
+// generated city 23.5 instead of 25.6).
+#define PT_SHADE_BLOCK 256
 #endif
 #define PT_INVALID 0xffffffffu
 
@@ -317,13 +327,17 @@ struct PtShadeArgs {
 	uint32_t path_length;
 	uint32_t k;       // 1-based path vertex; reads ext queue k - 1
 	uint32_t parity;  // ray queue of this bounce; the next one is parity ^ 1
+	uint32_t light_cache_capacity; // lights per thread in the dynamic LDS of the launch
 	unsigned long long* visit_counters; // [4] counts shaded hits, or NULL
 };
+
+// Dynamic LDS of k_shade: light_cache_capacity floats per thread
+extern __shared__ float pt_shade_light_importances[];
 
 // One instantiation per sampling strategy: the strategy is a compile-time
 // constant inside, so each kernel carries the registers of one estimator only
 template <int STRATEGY>
-__global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(PtShadeArgs a) {
+__global__ void __launch_bounds__(PT_SHADE_BLOCK, 5) k_shade(PtShadeArgs a) {
 	uint32_t first_slot;
 	uint32_t count = a.wf.ext_count[a.k - 1];
 	if (!pt_block_first_slot(count, &first_slot, PT_SHADE_BLOCK))
@@ -331,11 +345,10 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK) k_shade(PtShadeArgs a) {
 	pt_stage_srgb_table(a.scene.srgb_to_linear);
 	// Per-light importances of this thread's vertex between the two loops of
 	// pt_sample_lights(): lane-contiguous, hence free of bank conflicts
-	__shared__ float light_importances[(STRATEGY == PT_STRATEGY_NEE) ? PT_LIGHT_CACHE_SIZE * PT_SHADE_BLOCK : 1];
 	PtLightCache light_cache;
-	light_cache.values = &light_importances[(STRATEGY == PT_STRATEGY_NEE) ? threadIdx.x : 0];
+	light_cache.values = &pt_shade_light_importances[threadIdx.x];
 	light_cache.stride = PT_SHADE_BLOCK;
-	light_cache.capacity = (STRATEGY == PT_STRATEGY_NEE) ? PT_LIGHT_CACHE_SIZE : 0;
+	light_cache.capacity = (STRATEGY == PT_STRATEGY_NEE) ? a.light_cache_capacity : 0;
 	uint32_t slot = first_slot + threadIdx.x;
 	bool active = slot < count;
 	uint32_t path = PT_INVALID;
@@ -888,6 +901,9 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 	memset(&s->stats, 0, sizeof(s->stats));
 	int failed = 1;
 	do {
+		// More than 64 KB of dynamic LDS has to be asked for once
+		if (hipFuncSetAttribute((const void*) k_shade<PT_STRATEGY_NEE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (sizeof(float) * PT_SHADE_BLOCK * PT_LIGHT_CACHE_SIZE)) != hipSuccess)
+			break;
 		if (hipStreamCreate(&s->stream) != hipSuccess || hipStreamCreate(&s->shadow_stream) != hipSuccess
 			|| hipEventCreateWithFlags(&s->shade_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->shadow_done, hipEventDisableTiming) != hipSuccess)
 			break;
@@ -1165,15 +1181,18 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 			a.k = k;
 			a.parity = parity;
 			a.visit_counters = s->visit_counters_enabled ? s->visit_counters : NULL;
+			const bool tree = s->light_sampling == PT_LIGHT_SAMPLING_TREE && s->light_nodes;
+			a.light_cache_capacity = (s->strategy == PT_STRATEGY_NEE && !tree) ? (s->light_count < PT_LIGHT_CACHE_SIZE ? s->light_count : PT_LIGHT_CACHE_SIZE) : 0;
+			const size_t lds = sizeof(float) * PT_SHADE_BLOCK * a.light_cache_capacity;
 			switch (a.strategy) {
-			case PT_STRATEGY_SPHERICAL: hipLaunchKernelGGL(k_shade<PT_STRATEGY_SPHERICAL>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
-			case PT_STRATEGY_PSA: hipLaunchKernelGGL(k_shade<PT_STRATEGY_PSA>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
-			case PT_STRATEGY_BRDF: hipLaunchKernelGGL(k_shade<PT_STRATEGY_BRDF>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a); break;
+			case PT_STRATEGY_SPHERICAL: hipLaunchKernelGGL(k_shade<PT_STRATEGY_SPHERICAL>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a); break;
+			case PT_STRATEGY_PSA: hipLaunchKernelGGL(k_shade<PT_STRATEGY_PSA>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a); break;
+			case PT_STRATEGY_BRDF: hipLaunchKernelGGL(k_shade<PT_STRATEGY_BRDF>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a); break;
 			default:
-				if (s->light_sampling == PT_LIGHT_SAMPLING_TREE && s->light_nodes)
-					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE_TREE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a);
+				if (tree)
+					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE_TREE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a);
 				else
-					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), 0, s->stream, a);
+					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a);
 				break;
 			}
 		}

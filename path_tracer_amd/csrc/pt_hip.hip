@@ -50,6 +50,7 @@ static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device con
 // generated city 23.5 instead of 25.6).
 #define PT_SHADE_BLOCK 256
 #endif
+static_assert(sizeof(float) * PT_LIGHT_CACHE_SIZE * PT_SHADE_BLOCK <= 64 * 1024, "dynamic LDS beyond 64 KB has to be requested with hipFuncSetAttribute()");
 #define PT_INVALID 0xffffffffu
 
 #define PT_CHECK(call) do { hipError_t pt_err_ = (call); if (pt_err_ != hipSuccess) { \
@@ -901,9 +902,6 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 	memset(&s->stats, 0, sizeof(s->stats));
 	int failed = 1;
 	do {
-		// More than 64 KB of dynamic LDS has to be asked for once
-		if (hipFuncSetAttribute((const void*) k_shade<PT_STRATEGY_NEE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) (sizeof(float) * PT_SHADE_BLOCK * PT_LIGHT_CACHE_SIZE)) != hipSuccess)
-			break;
 		if (hipStreamCreate(&s->stream) != hipSuccess || hipStreamCreate(&s->shadow_stream) != hipSuccess
 			|| hipEventCreateWithFlags(&s->shade_done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s->shadow_done, hipEventDisableTiming) != hipSuccess)
 			break;

@@ -172,26 +172,34 @@ PT_FN void pt_build_radix_tree(const PtBuild& b, uint32_t index) {
 // boxes. arrive(flag_ptr) must be an atomic increment that returns the old
 // value and orders this thread's earlier box stores before it and its later
 // box loads after it (release/acquire at device scope).
-template <typename Arrive>
-PT_FN void pt_build_refit(const PtBuild& b, float pad, uint32_t k, Arrive arrive) {
-	uint32_t node = b.n - 1 + k;
-	float* box = &b.box[6 * (uint64_t) node];
+PT_FN void pt_build_leaf_box(const PtBuild& b, float pad, uint32_t k) {
+	float* box = &b.box[6 * (uint64_t) (b.n - 1 + k)];
 	float lo[3], hi[3];
 	pt_tri_box(&b.verts[9 * (uint64_t) b.order[k]], pad, lo, hi);
 	for (int j = 0; j != 3; ++j) { box[j] = lo[j]; box[3 + j] = hi[j]; }
+}
+
+// The box of an inner node from the boxes of its children
+PT_FN void pt_build_inner_box(const PtBuild& b, uint32_t node) {
+	const float* l = &b.box[6 * (uint64_t) b.left[node]];
+	const float* r = &b.box[6 * (uint64_t) b.right[node]];
+	float* out = &b.box[6 * (uint64_t) node];
+	for (int j = 0; j != 3; ++j) {
+		out[j] = fminf(l[j], r[j]);
+		out[3 + j] = fmaxf(l[j + 3], r[j + 3]);
+	}
+}
+
+template <typename Arrive>
+PT_FN void pt_build_refit(const PtBuild& b, float pad, uint32_t k, Arrive arrive) {
+	pt_build_leaf_box(b, pad, k);
 	if (b.n < 2)
 		return;
-	uint32_t parent = b.parent[node];
+	uint32_t parent = b.parent[b.n - 1 + k];
 	while (parent != 0xffffffffu) {
 		if (arrive(&b.flags[parent]) == 0)
 			return;
-		const float* l = &b.box[6 * (uint64_t) b.left[parent]];
-		const float* r = &b.box[6 * (uint64_t) b.right[parent]];
-		float* out = &b.box[6 * (uint64_t) parent];
-		for (int j = 0; j != 3; ++j) {
-			out[j] = fminf(l[j], r[j]);
-			out[3 + j] = fmaxf(l[j + 3], r[j + 3]);
-		}
+		pt_build_inner_box(b, parent);
 		parent = b.parent[parent];
 	}
 }

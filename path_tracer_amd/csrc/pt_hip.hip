@@ -121,13 +121,25 @@ __global__ void __launch_bounds__(PT_BLOCK) k_build_refit(PtBuild b) {
 	pt_build_refit(b, sb.pad, k, [](uint32_t* flag) { return pt_build_arrive(flag); });
 }
 
-// One pass of treelet restructuring over the whole binary tree
+// One pass of treelet restructuring over the whole binary tree. The first
+// pass computes the boxes on its way up as well (WITH_BOXES), which saves the
+// separate pass of k_build_refit: a node's box is final before its treelet is
+// formed, and the treelets below it have not changed the boxes of their roots.
+template <bool WITH_BOXES>
 __global__ void __launch_bounds__(PT_BLOCK) k_build_treelets(PtBuild b) {
 	uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
 	if (k >= b.n)
 		return;
+	if (WITH_BOXES) {
+		PtSceneBounds sb = pt_build_get_bounds(b.bounds);
+		pt_build_leaf_box(b, sb.pad, k);
+	}
 	PtTreeletScratch scratch;
-	pt_build_climb(b, k, pt_build_arrive, [&](uint32_t node) { pt_build_treelet(b, node, scratch); });
+	pt_build_climb(b, k, pt_build_arrive, [&](uint32_t node) {
+		if (WITH_BOXES)
+			pt_build_inner_box(b, node);
+		pt_build_treelet(b, node, scratch);
+	});
 }
 
 // Costs and choices of the wide collapse, bottom-up over the final binary tree
@@ -790,15 +802,21 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 		{ uint32_t* t = b.order; b.order = order_sorted; order_sorted = t; }
 		if (n > 1)
 			hipLaunchKernelGGL(k_build_radix_tree, dim3(pt_grid(n - 1)), dim3(PT_BLOCK), 0, s->stream, b);
-		hipLaunchKernelGGL(k_build_refit, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+		// Boxes bottom-up, on their own only if no treelet pass does it on its way
+		// (the flags are still zero here)
+		if (PT_TREELET_PASSES == 0 || n < 2)
+			hipLaunchKernelGGL(k_build_refit, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
 		// Treelet restructuring passes, then the costs of the wide collapse
 		bool passes_failed = false;
 		for (int pass = 0; pass <= PT_TREELET_PASSES && n > 1 && !passes_failed; ++pass) {
-			passes_failed = hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * n, s->stream) != hipSuccess;
+			// The first pass finds the flags zeroed above unless k_build_refit has used them
+			passes_failed = (pass != 0 || PT_TREELET_PASSES == 0) && hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * n, s->stream) != hipSuccess;
 			if (passes_failed)
 				break;
-			if (pass < PT_TREELET_PASSES)
-				hipLaunchKernelGGL(k_build_treelets, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+			if (pass == 0 && PT_TREELET_PASSES > 0)
+				hipLaunchKernelGGL(k_build_treelets<true>, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+			else if (pass < PT_TREELET_PASSES)
+				hipLaunchKernelGGL(k_build_treelets<false>, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
 			else
 				hipLaunchKernelGGL(k_build_wide_costs, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
 		}

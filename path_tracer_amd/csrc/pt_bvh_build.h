@@ -252,7 +252,9 @@ PT_FN float pt_box_area(const float* box) {
 #ifndef PT_TREELET_PASSES
 #define PT_TREELET_PASSES 1
 #endif
+#ifndef PT_SAH_NODE_COST
 #define PT_SAH_NODE_COST 1.2f
+#endif
 #define PT_SAH_TRIANGLE_COST 1.0f
 
 struct PtTreeletScratch {

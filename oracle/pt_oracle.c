@@ -858,7 +858,7 @@ static float get_lights_density(const context_t* ctx, float total_importance, ve
    centre and half extents of the box around its spheres, the sum of their
    squared radii and the squared half diagonal (8 floats). */
 typedef struct {
-	float coordinate;
+	uint32_t coordinate; /* bit pattern of the float, mapped to sort like the number */
 	uint32_t index;
 } light_key_t;
 
@@ -897,7 +897,8 @@ static void place_lights(const float* lights, uint32_t* indices, size_t count, f
 	}
 	light_key_t* keys = (light_key_t*) malloc(sizeof(light_key_t) * count);
 	for (size_t i = 0; i != count; ++i) {
-		keys[i].coordinate = lights[4 * (size_t) indices[i] + axis];
+		uint32_t bits = float_to_bits(lights[4 * (size_t) indices[i] + axis]);
+		keys[i].coordinate = (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
 		keys[i].index = indices[i];
 	}
 	qsort(keys, count, sizeof(light_key_t), compare_light_keys);

@@ -39,6 +39,13 @@ struct PtLightTree {
 	std::vector<f32x4> lights; // the light of every leaf; empty leaves are zero
 };
 
+// Unsigned integers in the order of the floats they are made from (-0 before
+// +0, NaN beyond the infinities)
+static inline uint32_t pt_light_sort_key(float value) {
+	uint32_t bits = pt_as_uint(value);
+	return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u);
+}
+
 // Places the lights order[begin, end) in a subtree that has
 // slot_count leaf slots, starting at leaf slot first_slot
 static inline void pt_place_lights(PtLightTree& tree, const float* lights, std::vector<uint32_t>& order, size_t begin, size_t end, size_t first_slot, size_t slot_count) {
@@ -64,8 +71,10 @@ static inline void pt_place_lights(PtLightTree& tree, const float* lights, std::
 			axis = a;
 		}
 	}
+	// Sorted by the bit pattern mapped so that it orders like the number: a
+	// total order even if a coordinate is NaN
 	std::sort(order.begin() + begin, order.begin() + end, [&](uint32_t lhs, uint32_t rhs) {
-		float l = lights[4 * (size_t) lhs + axis], r = lights[4 * (size_t) rhs + axis];
+		uint32_t l = pt_light_sort_key(lights[4 * (size_t) lhs + axis]), r = pt_light_sort_key(lights[4 * (size_t) rhs + axis]);
 		return (l != r) ? (l < r) : (lhs < rhs);
 	});
 	size_t left_count = (end - begin + 1) / 2;

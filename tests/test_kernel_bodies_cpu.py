@@ -202,6 +202,13 @@ def test_light_tree_degenerate_lights():
         assert rays_a == rays_b
         assert ((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all()
         assert np.isfinite(a).all()
+    # Lights that are not numbers must not break the builders (their sort needs a total order); what they render
+    # is as undefined as in the reference, where a NaN importance poisons the sum over all lights
+    lights = np.array([[1, 2, 3, 0.5], [np.nan, 0, 0, 0.2], [0, np.inf, 0, 0.1], [4, 4, 4, np.nan], [-2, 1, 0, 0.3]] * 3, np.float32)
+    e_scene.set_lights(lights)
+    constants = oracle.write_constants(spec, 24, 16, scene, lights[:1])
+    o_scene.render(constants, lights, strategy=3, path_length=3, first_frame_index=1, frame_count=1, light_sampling=1)
+    e_scene.render(constants, strategy=4, path_length=3, first_frame_index=1, frame_count=1)
 
 
 def test_light_tree_converges_to_the_loop_over_all_lights():

@@ -99,55 +99,83 @@ __global__ void __launch_bounds__(PT_BLOCK) k_build_radix_tree(PtBuild b) {
 		pt_build_radix_tree(b, i);
 }
 
-// Arrival at an inner node during a bottom-up pass: the counter orders this
-// thread's stores before it and its later loads after it at device scope
-__device__ __forceinline__ uint32_t pt_build_arrive(uint32_t* flag) {
-	// Release for both threads that arrive (their stores have to be visible to
-	// whoever continues upwards), acquire only for the second, which goes on to
-	// read what the first has written. Two full fences around a relaxed atomic
-	// do the same and cost a third more build time: every fence writes back
-	// and invalidates the L2 of the XCD it runs on.
-	uint32_t old = __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-	if (old != 0)
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-	return old;
+// Bottom-up passes over the binary tree (boxes, treelets, costs of the wide
+// collapse) run in rounds: a round works on the queue of inner nodes whose
+// children are both done, one node per thread, and fills the queue of the
+// next round with the parents that this makes ready (the second thread to
+// arrive at a parent enqueues it). Threads of a wave thus work on different
+// nodes of about the same height at the same time. Climbing from every leaf
+// in one launch instead (the second thread to arrive goes on to the parent)
+// leaves one busy lane per wave after a few levels and needs a device-scope
+// release and acquire per arrival, which on this part write back and
+// invalidate the L2 of the XCD: that took six times as long.
+enum { PT_PASS_BOXES = 1, PT_PASS_TREELETS = 2, PT_PASS_WIDE_COSTS = 4 };
+
+// Appends value to a queue for the lanes that want it, one atomic per wave.
+// All lanes of the wave must call this.
+__device__ __forceinline__ void pt_queue_push(uint32_t* queue, uint32_t* count, bool want, uint32_t value) {
+	unsigned long long mask = __ballot(want);
+	if (mask == 0)
+		return;
+	int leader = __builtin_ctzll(mask);
+	uint32_t base = 0;
+	if ((int) (threadIdx.x & 63) == leader)
+		base = atomicAdd(count, (uint32_t) __popcll(mask));
+	base = (uint32_t) __shfl((int) base, leader);
+	if (want)
+		queue[base + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u))] = value;
 }
 
-__global__ void __launch_bounds__(PT_BLOCK) k_build_refit(PtBuild b) {
-	uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
-	if (k >= b.n)
-		return;
-	PtSceneBounds sb = pt_build_get_bounds(b.bounds);
-	pt_build_refit(b, sb.pad, k, [](uint32_t* flag) { return pt_build_arrive(flag); });
+// Arrival at the parent of a finished node: true for the second of its children
+__device__ __forceinline__ bool pt_build_arrive_second(const PtBuild& b, uint32_t parent) {
+	return parent != 0xffffffffu && atomicAdd(&b.flags[parent], 1u) == 1u;
 }
 
-// One pass of treelet restructuring over the whole binary tree. The first
-// pass computes the boxes on its way up as well (WITH_BOXES), which saves the
-// separate pass of k_build_refit: a node's box is final before its treelet is
-// formed, and the treelets below it have not changed the boxes of their roots.
-template <bool WITH_BOXES>
-__global__ void __launch_bounds__(PT_BLOCK) k_build_treelets(PtBuild b) {
+// Round 0: the leaves. The flags must be zero.
+template <int PASS>
+__global__ void __launch_bounds__(PT_BLOCK) k_build_round_leaves(PtBuild b, uint32_t* queue_out, uint32_t* count_out) {
 	uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
-	if (k >= b.n)
-		return;
-	if (WITH_BOXES) {
-		PtSceneBounds sb = pt_build_get_bounds(b.bounds);
-		pt_build_leaf_box(b, sb.pad, k);
+	bool push = false;
+	uint32_t parent = 0xffffffffu;
+	if (k < b.n) {
+		if (PASS & PT_PASS_BOXES) {
+			PtSceneBounds sb = pt_build_get_bounds(b.bounds);
+			pt_build_leaf_box(b, sb.pad, k);
+		}
+		// A single triangle has no inner node above it
+		if (b.n > 1) {
+			parent = b.parent[b.n - 1 + k];
+			push = pt_build_arrive_second(b, parent);
+		}
 	}
-	PtTreeletScratch scratch;
-	pt_build_climb(b, k, pt_build_arrive, [&](uint32_t node) {
-		if (WITH_BOXES)
-			pt_build_inner_box(b, node);
-		pt_build_treelet(b, node, scratch);
-	});
+	pt_queue_push(queue_out, count_out, push, parent);
 }
 
-// Costs and choices of the wide collapse, bottom-up over the final binary tree
-__global__ void __launch_bounds__(PT_BLOCK) k_build_wide_costs(PtBuild b) {
-	uint32_t k = blockIdx.x * PT_BLOCK + threadIdx.x;
-	if (k >= b.n)
-		return;
-	pt_build_climb(b, k, pt_build_arrive, [&](uint32_t node) { pt_build_wide_cost(b, node); });
+// Later rounds: the inner nodes of queue_in (count_in is the counter that the
+// previous round has left behind)
+template <int PASS>
+__global__ void __launch_bounds__(PT_BLOCK) k_build_round(PtBuild b, const uint32_t* queue_in, const uint32_t* count_in, uint32_t* queue_out, uint32_t* count_out) {
+	const uint32_t count = *count_in;
+	const uint32_t stride = gridDim.x * PT_BLOCK;
+	PtTreeletScratch scratch;
+	// Whole waves leave the loop together, so that every lane takes part in the pushes
+	for (uint32_t first = blockIdx.x * PT_BLOCK + (threadIdx.x & ~63u); first < count; first += stride) {
+		uint32_t i = first + (threadIdx.x & 63u);
+		bool push = false;
+		uint32_t parent = 0xffffffffu;
+		if (i < count) {
+			uint32_t node = queue_in[i];
+			if (PASS & PT_PASS_BOXES)
+				pt_build_inner_box(b, node);
+			if (PASS & PT_PASS_TREELETS)
+				pt_build_treelet(b, node, scratch);
+			if (PASS & PT_PASS_WIDE_COSTS)
+				pt_build_wide_cost(b, node);
+			parent = b.parent[node];
+			push = pt_build_arrive_second(b, parent);
+		}
+		pt_queue_push(queue_out, count_out, push, parent);
+	}
 }
 
 __global__ void __launch_bounds__(PT_BLOCK) k_build_collapse(PtBuild b, uint32_t level_begin, uint32_t level_end) {
@@ -742,6 +770,40 @@ static int pt_reserve_wavefront(pt_scene* s, uint32_t path_count) {
 	return 0;
 }
 
+// One bottom-up pass over the binary tree in rounds (see k_build_round).
+// queues are two arrays of n node indices, counts two counters on the device.
+template <int PASS>
+static int pt_build_bottom_up(pt_scene* s, const PtBuild& b, uint32_t* queues[2], uint32_t* counts) {
+	const uint32_t n = b.n;
+	PT_CHECK(hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * n, s->stream));
+	PT_CHECK(hipMemsetAsync(counts, 0, 2 * sizeof(uint32_t), s->stream));
+	hipLaunchKernelGGL(k_build_round_leaves<PASS>, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b, queues[0], &counts[0]);
+	int in = 0;
+	uint32_t round = 1, remaining = n > 1 ? 1u : 0u;
+	while (remaining != 0) {
+		// No tree is deeper than its 63-bit keys and 32-bit indices allow
+		if (round > 4096) {
+			printf("A bottom-up pass over the BVH did not come to an end.\n");
+			return 1;
+		}
+		// Sixteen rounds between looks at the queue; rounds on an empty queue do nothing
+		for (int i = 0; i != 16; ++i, ++round) {
+			PT_CHECK(hipMemsetAsync(&counts[in ^ 1], 0, sizeof(uint32_t), s->stream));
+			// A node done in round r has at least r + 1 leaves below it, so at most
+			// n / (r + 1) nodes queue up; the kernel strides over whatever there is
+			uint32_t blocks = pt_grid(n / (round + 1) + 1);
+			if (blocks > 16384)
+				blocks = 16384;
+			hipLaunchKernelGGL(k_build_round<PASS>, dim3(blocks), dim3(PT_BLOCK), 0, s->stream, b, (const uint32_t*) queues[in], (const uint32_t*) &counts[in], queues[in ^ 1], &counts[in ^ 1]);
+			in ^= 1;
+		}
+		PT_CHECK(hipMemcpyAsync(&remaining, &counts[in], sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream));
+		PT_CHECK(hipStreamSynchronize(s->stream));
+	}
+	PT_CHECK(hipGetLastError());
+	return 0;
+}
+
 static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 	uint32_t n = s->triangle_count;
 	hipEvent_t begin, end;
@@ -756,6 +818,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 	memcpy(b.summand, header->dequantization_summand, sizeof(b.summand));
 	uint64_t* keys_sorted = NULL;
 	uint32_t* order_sorted = NULL;
+	uint32_t* round_counts = NULL;
 	void* sort_temp = NULL;
 	int result = 1;
 	// The wide BVH has at most one node per two leaf groups; n nodes is a safe bound
@@ -777,7 +840,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 			|| pt_alloc(&keys_sorted, n) || pt_alloc(&order_sorted, n)
 			|| pt_alloc(&b.left, n) || pt_alloc(&b.right, n) || pt_alloc(&b.parent, 2 * (uint64_t) n)
 			|| pt_alloc(&b.size, n) || pt_alloc(&b.sah_cost, n) || pt_alloc(&b.wide_cost, 8 * (uint64_t) n) || pt_alloc(&b.wide_choice, 8 * (uint64_t) n) || pt_alloc(&b.box, 12 * (uint64_t) n)
-			|| pt_alloc(&b.flags, n) || pt_alloc(&b.task_binary, max_nodes) || pt_alloc(&b.counters, 2))
+			|| pt_alloc(&b.flags, n) || pt_alloc(&b.task_binary, max_nodes) || pt_alloc(&b.counters, 2) || pt_alloc(&round_counts, 2))
 			break;
 		b.nodes = s->nodes;
 		b.tris = s->tris;
@@ -802,23 +865,20 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 		{ uint32_t* t = b.order; b.order = order_sorted; order_sorted = t; }
 		if (n > 1)
 			hipLaunchKernelGGL(k_build_radix_tree, dim3(pt_grid(n - 1)), dim3(PT_BLOCK), 0, s->stream, b);
-		// Boxes bottom-up, on their own only if no treelet pass does it on its way
-		// (the flags are still zero here)
-		if (PT_TREELET_PASSES == 0 || n < 2)
-			hipLaunchKernelGGL(k_build_refit, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
-		// Treelet restructuring passes, then the costs of the wide collapse
+		// Bottom-up passes in rounds (the old key array serves as the two queues):
+		// boxes with the first treelet pass, further treelet passes, then the
+		// costs of the wide collapse
+		uint32_t* queues[2] = { (uint32_t*) keys_sorted, (uint32_t*) keys_sorted + n };
 		bool passes_failed = false;
-		for (int pass = 0; pass <= PT_TREELET_PASSES && n > 1 && !passes_failed; ++pass) {
-			// The first pass finds the flags zeroed above unless k_build_refit has used them
-			passes_failed = (pass != 0 || PT_TREELET_PASSES == 0) && hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * n, s->stream) != hipSuccess;
-			if (passes_failed)
-				break;
-			if (pass == 0 && PT_TREELET_PASSES > 0)
-				hipLaunchKernelGGL(k_build_treelets<true>, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+		for (int pass = 0; pass <= PT_TREELET_PASSES && !passes_failed; ++pass) {
+			if (PT_TREELET_PASSES == 0)
+				passes_failed = pt_build_bottom_up<PT_PASS_BOXES | PT_PASS_WIDE_COSTS>(s, b, queues, round_counts) != 0;
+			else if (pass == 0)
+				passes_failed = pt_build_bottom_up<PT_PASS_BOXES | PT_PASS_TREELETS>(s, b, queues, round_counts) != 0;
 			else if (pass < PT_TREELET_PASSES)
-				hipLaunchKernelGGL(k_build_treelets<false>, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+				passes_failed = pt_build_bottom_up<PT_PASS_TREELETS>(s, b, queues, round_counts) != 0;
 			else
-				hipLaunchKernelGGL(k_build_wide_costs, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+				passes_failed = pt_build_bottom_up<PT_PASS_WIDE_COSTS>(s, b, queues, round_counts) != 0;
 		}
 		if (passes_failed)
 			break;
@@ -856,7 +916,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 	hipEventDestroy(end);
 	hipFree(b.verts); hipFree(b.bounds); hipFree(b.keys); hipFree(b.order); hipFree(keys_sorted); hipFree(order_sorted);
 	hipFree(b.left); hipFree(b.right); hipFree(b.parent); hipFree(b.size); hipFree(b.sah_cost); hipFree(b.wide_cost); hipFree(b.wide_choice); hipFree(b.box);
-	hipFree(b.flags); hipFree(b.task_binary); hipFree(b.counters); hipFree(sort_temp);
+	hipFree(b.flags); hipFree(b.task_binary); hipFree(b.counters); hipFree(round_counts); hipFree(sort_temp);
 	s->bvh_info.node_bytes = sizeof(PtNode);
 	s->bvh_info.triangle_bytes = sizeof(PtTri);
 	if (result)

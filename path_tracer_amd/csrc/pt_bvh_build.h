@@ -318,25 +318,24 @@ PT_FN void pt_build_treelet(const PtBuild& b, uint32_t root, PtTreeletScratch& t
 		pt_build_union_of(b, leaves, subset, box);
 		t.area[subset] = pt_box_area(box);
 	}
-	// Cheapest binary tree over every subset, small subsets first
+	// Cheapest binary tree over every subset. In numerical order every proper
+	// subset of a set comes before the set, so its cost is known by then.
 	for (uint32_t i = 0; i != leaf_count; ++i)
 		t.cost[1u << i] = pt_build_subtree_cost(b, leaves[i]);
-	for (uint32_t count = 2; count <= leaf_count; ++count) {
-		for (uint32_t subset = 1; subset <= full; ++subset) {
-			if ((uint32_t) pt_popc(subset) != count)
-				continue;
-			// Partitions (p, subset ^ p): p runs over the subsets of the rest that
-			// leave out the lowest leaf, so every split is seen once
-			uint32_t rest = subset & (subset - 1u);
-			float best = INFINITY;
-			uint32_t best_p = rest;
-			for (uint32_t p = rest; p != 0; p = (p - 1u) & rest) {
-				float c = t.cost[p] + t.cost[subset ^ p];
-				if (c < best) { best = c; best_p = p; }
-			}
-			t.cost[subset] = PT_SAH_NODE_COST * t.area[subset] + best;
-			t.partition[subset] = (uint8_t) best_p;
+	for (uint32_t subset = 3; subset <= full; ++subset) {
+		// Partitions (p, subset ^ p): p runs over the subsets of the rest that
+		// leave out the lowest leaf, so every split is seen once
+		uint32_t rest = subset & (subset - 1u);
+		if (rest == 0)
+			continue;
+		float best = INFINITY;
+		uint32_t best_p = rest;
+		for (uint32_t p = rest; p != 0; p = (p - 1u) & rest) {
+			float c = t.cost[p] + t.cost[subset ^ p];
+			if (c < best) { best = c; best_p = p; }
 		}
+		t.cost[subset] = PT_SAH_NODE_COST * t.area[subset] + best;
+		t.partition[subset] = (uint8_t) best_p;
 	}
 	// Keep the present topology unless the best one is cheaper
 	if (!(t.cost[full] < b.sah_cost[root]))

@@ -70,11 +70,19 @@ __device__ __forceinline__ float pt_wave_max(float v) {
 	return v;
 }
 
+// A grid of fixed size strides over the triangles, so that the atomics on the
+// six words of the scene bounds stay few (one set per wave of the grid, not
+// per 64 triangles: same-address atomics are served one after the other)
 __global__ void __launch_bounds__(PT_BLOCK) k_build_dequantize(PtBuild b) {
-	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
 	float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
-	if (i < b.n)
-		pt_build_dequantize(b, i, lo, hi);
+	for (uint64_t i = blockIdx.x * PT_BLOCK + threadIdx.x; i < b.n; i += (uint64_t) gridDim.x * PT_BLOCK) {
+		float tri_lo[3], tri_hi[3];
+		pt_build_dequantize(b, (uint32_t) i, tri_lo, tri_hi);
+		for (int j = 0; j != 3; ++j) {
+			lo[j] = fminf(lo[j], tri_lo[j]);
+			hi[j] = fmaxf(hi[j], tri_hi[j]);
+		}
+	}
 	for (int j = 0; j != 3; ++j) {
 		float l = pt_wave_min(lo[j]), h = pt_wave_max(hi[j]);
 		if ((threadIdx.x & 63) == 0) {
@@ -852,7 +860,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 			|| hipMemcpyAsync(b.task_binary, &root_task, sizeof(root_task), hipMemcpyHostToDevice, s->stream) != hipSuccess
 			|| hipMemsetAsync(b.flags, 0, sizeof(uint32_t) * n, s->stream) != hipSuccess)
 			break;
-		hipLaunchKernelGGL(k_build_dequantize, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
+		hipLaunchKernelGGL(k_build_dequantize, dim3(pt_grid(n) < 4096 ? pt_grid(n) : 4096), dim3(PT_BLOCK), 0, s->stream, b);
 		hipLaunchKernelGGL(k_build_morton, dim3(pt_grid(n)), dim3(PT_BLOCK), 0, s->stream, b);
 		size_t temp_bytes = 0;
 		if (rocprim::radix_sort_pairs(NULL, temp_bytes, b.keys, keys_sorted, b.order, order_sorted, n, 0, 63, s->stream) != hipSuccess)

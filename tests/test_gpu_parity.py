@@ -380,3 +380,30 @@ def test_command_line_driver(tmp_path):
     done = subprocess.run([binary, "-no_such_option"], capture_output=True, text=True, timeout=60)
     assert done.returncode != 0 and "Usage" in done.stdout
     renderer.close()
+
+
+def test_committed_vectors(cornell, cornell_lights, cornell_spec):
+    """The library against the committed renders of tests/golden/vectors (written by tests/golden/make_vectors.py from
+    the oracle): no oracle code runs here."""
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_vectors", os.path.join(here, "make_vectors.py"))
+    mv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mv)
+    expected_rays = dict(line.split() for line in open(os.path.join(here, "vectors", "ray_counts.txt")))
+    g_scene = gpu_scene(cornell, cornell_lights)
+    constants = to_gpu_constants(oracle.write_constants(cornell_spec, mv.WIDTH, mv.HEIGHT, cornell, cornell_lights))
+    g_scene.create_render_targets(mv.WIDTH, mv.HEIGHT)
+    for name, strategy, light_sampling, extra in mv.CASES:
+        lights = np.concatenate([cornell_lights, np.array(mv.EXTRA_LIGHTS[:extra], np.float32).reshape(-1, 4)])
+        g_scene.set_lights(lights)
+        g_scene.set_light_sampling(light_sampling)
+        g_scene.set_render_settings(strategy, mv.PATH_LENGTH, cornell.emission_material_index)
+        g_scene.reset_statistics()
+        g_scene.render_samples(constants, mv.FIRST_FRAME, mv.FRAMES, 1, accumulate=False)
+        got, count = g_scene.read_accumulation()
+        stats = g_scene.statistics()
+        expected = np.load(os.path.join(here, "vectors", "cornell_%s.npy" % name))
+        assert count == mv.FRAMES and stats.extension_rays + stats.shadow_rays == int(expected_rays[name]), name
+        assert (bits(got) == bits(expected)).all(), name
+    g_scene.close()

@@ -238,3 +238,19 @@ def test_path_length_semantics(cornell, cornell_lights, cornell_spec, oracle_cor
     colours = np.unique(emission_only[..., :3].reshape(-1, 3), axis=0)
     assert len(colours) == 2 and (colours[0] == 0).all()
     np.testing.assert_allclose(colours[1], [20.0, 18.0, 12.0], rtol=1e-6)
+
+
+def test_oracle_regression_vectors():
+    """The oracle against renders it produced when they were committed (tests/golden/make_vectors.py): not a pin by
+    the reference, but one that a change altering oracle and HIP library alike cannot pass unnoticed."""
+    import importlib.util
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_vectors", os.path.join(here, "make_vectors.py"))
+    make_vectors = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(make_vectors)
+    expected_rays = dict(line.split() for line in open(os.path.join(here, "vectors", "ray_counts.txt")))
+    for name, image, rays in make_vectors.render_cases():
+        expected = np.load(os.path.join(here, "vectors", "cornell_%s.npy" % name))
+        assert rays == int(expected_rays[name]), name
+        assert (image.view(np.uint32) == expected.view(np.uint32)).all(), name
+        assert image[..., :3].max() > 0

@@ -34,9 +34,11 @@ def workload_root(args, rank, barrier=None):
         return DATA_ROOT
     from path_tracer_amd.tools import procedural
     triangles = args.triangles or WORKLOADS[args.workload][4]
-    root = os.path.join(args.scene_cache, "%s_%d" % (args.workload, triangles))
+    root = os.path.join(args.scene_cache, "%s_%d%s" % (args.workload, triangles, "_t%d" % args.texture_size if args.texture_size else ""))
     if rank == 0:
         options = {"triangles": triangles}
+        if args.texture_size:
+            options["texture_size"] = args.texture_size
         if args.workload == "city":
             options["lights_file"] = os.path.join(DATA_ROOT, "data", "Bistro_outside.lights")
             options["save_file"] = os.path.join(DATA_ROOT, "data", "saves", "bistro", "outside.rt_save")
@@ -62,6 +64,7 @@ def parse_args():
     p.add_argument("--workload", choices=sorted(WORKLOADS), default="cornell",
                    help="cornell: the reference's own scene file; city / interior: generated stand-ins for Bistro exterior / Arcade")
     p.add_argument("--triangles", type=int, default=None, help="triangle budget of a generated workload")
+    p.add_argument("--texture-size", type=int, default=None, help="edge length of the textures of a generated workload (default 256)")
     p.add_argument("--lights", type=int, default=None,
                    help="replace the workload's lights by this many spheres placed uniformly in the scene's bounding box (seed 4, radius 0.1 to 0.5)")
     p.add_argument("--light-sampling", choices=("loop", "tree"), default="loop",

@@ -83,15 +83,14 @@ def trace_bytes_per_ray(kind, nodes_per_ray, tris_per_ray, node_bytes, tri_bytes
     return stream + nodes_per_ray * node_bytes + tris_per_ray * tri_bytes
 
 
-def measured_hbm_traffic(workload, kernel):
-    """HBM bytes per launch of a kernel from the committed counter passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
-    this benchmark, scripts/gpu_pmc.sh + scripts/pmc_to_json.py), or None. Counters cannot be read inside the timed run."""
+def measured_counters(workload, kernel):
+    """Per-launch hardware counters of a kernel from the committed counter passes (rocprofv3 --pmc runs of this
+    benchmark, scripts/gpu_pmc.sh + scripts/pmc_to_json.py), or None. Counters cannot be read inside the timed run."""
     path = os.path.join(ROOT, "profiles", "pmc_current.json")
     if not os.path.exists(path):
         return None
     with open(path) as file:
-        entry = json.load(file).get(workload, {}).get("kernels", {}).get(kernel)
-    return entry["hbm_bytes_per_launch"] if entry else None
+        return json.load(file).get(workload, {}).get("kernels", {}).get(kernel)
 
 
 def generated_lights(count, factor, summand):
@@ -233,6 +232,10 @@ def main():
                              "achieved_gbs": bytes_per_ray * timed_rays / launches / (avg_ms * 1e-3) * 1e-9}
         dominant = max(kernels, key=lambda k: kernels[k]["total_ms"])
         d = kernels[dominant]
+        # Counters exist for the configurations that were profiled: the default batch of the workloads as they are
+        profiled = spp == 32 and not args.triangles and args.lights is None and not args.texture_size and args.light_sampling == "loop" \
+            and (args.width, args.height, args.path_length) == (1920, 1080, 4)
+        counters = measured_counters(args.workload, "k_trace_%s<false>" % dominant) if profiled else None
         result = {
             "metric": "Mrays/s", "value": total_rays / seconds * 1e-6, "unit": "Mrays/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": seconds / args.steps * 1e3,
@@ -246,10 +249,17 @@ def main():
             "rays_per_path": total_rays / total_paths,
             "roofline": {"bound": "hbm", "kernel": "k_trace_%s" % dominant, "achieved": d["achieved_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": d["achieved_gbs"] / HBM_PEAK_GBS,
-                         "traffic": measured_hbm_traffic(args.workload, "k_trace_%s<false>" % dominant) if (spp == 32 and not args.triangles) else None,
+                         "traffic": counters["hbm_bytes_per_launch"] if counters else None,
                          "algorithmic_bytes_per_launch": d["bytes_per_ray"] * d["rays_per_launch"],
                          "avg_launch_ms": d["avg_ms"], "rays_per_launch": d["rays_per_launch"], "bytes_per_ray": d["bytes_per_ray"],
-                         "nodes_per_ray": d["nodes_per_ray"], "triangles_per_ray": d["tris_per_ray"]},
+                         "nodes_per_ray": d["nodes_per_ray"], "triangles_per_ray": d["tris_per_ray"],
+                         # What the counters say about the kernel besides bytes: VALU instructions per launch (per wave) and
+                         # the share of lanes active in them; a SIMD issues one wave instruction every two cycles (32 lanes
+                         # a cycle), so at 2.4 GHz the 1024 SIMDs issue at most 1.23e12 a second
+                         "valu_instructions_per_launch": counters["valu_instructions_per_launch"] if counters else None,
+                         "valu_lane_utilisation": counters["valu_lane_utilisation"] if counters else None,
+                         "valu_issue_frac": (counters["valu_instructions_per_launch"] / (d["avg_ms"] * 1e-3) / 1.2288e12) if counters else None,
+                         "l2_hit_rate": counters["l2_hit_rate"] if counters else None},
             "kernel_ms": {name: stats.kernel_ms[i] for i, name in enumerate(hip_api.KERNEL_NAMES)},
             "bvh": {"nodes": info.node_count, "triangles": info.triangle_count, "depth": info.depth, "build_ms": info.build_ms},
         }

@@ -29,6 +29,8 @@
 #include <rocprim/rocprim.hpp>
 #include <stdio.h>
 #include <stdlib.h>
+#include <exception>
+#include <new>
 #include <vector>
 
 static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device constants must agree");
@@ -55,6 +57,24 @@ static_assert(sizeof(float) * PT_LIGHT_CACHE_SIZE * PT_SHADE_BLOCK <= 64 * 1024,
 
 #define PT_CHECK(call) do { hipError_t pt_err_ = (call); if (pt_err_ != hipSuccess) { \
 	printf("HIP error %s at %s:%d (%s).\n", hipGetErrorString(pt_err_), __FILE__, __LINE__, #call); return 1; } } while (0)
+
+// Runs the body of an entry point of the C ABI. The callers are C: no
+// exception (std::bad_alloc of a std::vector sized by the caller's data, for
+// instance) may cross the boundary, so it becomes a message and a nonzero
+// return code like every other failure.
+template <typename Body>
+static int pt_guarded(const char* function_name, Body body) {
+	try {
+		return body();
+	}
+	catch (const std::exception& e) {
+		printf("%s() failed: %s.\n", function_name, e.what());
+	}
+	catch (...) {
+		printf("%s() failed with an unknown exception.\n", function_name);
+	}
+	return 1;
+}
 
 
 // ---------------------------------------------------------------- BVH build
@@ -254,6 +274,7 @@ struct PtTraceArgs {
 	uint32_t* fetch;  // 8 zeroed fetch counters for this launch
 	PtCacheLayout cache_layout;
 	unsigned long long* visit_counters; // nodes, triangles of extension rays [0], [1] and of shadow rays [2], [3], or NULL
+	uint32_t* error_word; // PT_ERROR_* bits, checked by pt_synchronize()
 };
 
 // pathtrace.frag.glsl:365-386 for every path of the batch
@@ -291,7 +312,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_extension(PtTraceArgs 
 	queue.fetch = a.fetch;
 	u32x4* hits = a.wf.hit;
 	pt_trace_wave<COUNT_VISITS>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
-		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters,
+		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters, a.error_word,
 		[&](uint32_t slot, float path_bits, float, const PtHit& hit) {
 			// Triangle indices stay below 2^31, so the front flag rides in the top
 			// bit (a miss is all ones); the path index comes along so that shading
@@ -316,7 +337,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_shadow(PtTraceArgs a) 
 	queue.count = &a.wf.shadow_count[a.bounce];
 	queue.fetch = a.fetch;
 	pt_trace_wave<COUNT_VISITS>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
-		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters ? a.visit_counters + 2 : NULL,
+		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters ? a.visit_counters + 2 : NULL, a.error_word,
 		[&](uint32_t slot, float path_bits, float factor, const PtHit& hit) {
 			const PtConstants& c = *a.constants;
 			v3 emission;
@@ -512,6 +533,7 @@ struct PtUserRayArgs {
 	u32x2* stack_overflow;
 	uint32_t stack_overflow_stride, stack_capacity;
 	PtCacheLayout cache_layout;
+	uint32_t* error_word;
 	int32_t* triangles;
 	float* t_u_v;
 	uint8_t* front;
@@ -526,7 +548,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_user_rays(PtUserRayArg
 	queue.count = a.count;
 	queue.fetch = a.fetch;
 	pt_trace_wave<false>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
-		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, NULL,
+		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, NULL, a.error_word,
 		[&](uint32_t slot, float, float, const PtHit& hit) {
 			a.triangles[slot] = (int32_t) hit.prim;
 			a.t_u_v[3 * slot] = hit.t;
@@ -612,6 +634,7 @@ struct pt_scene {
 	hipStream_t shadow_stream;
 	hipEvent_t shade_done, shadow_done;
 	unsigned long long* visit_counters;
+	uint32_t* error_word; // device word of PT_ERROR_* bits
 	// pinned host staging for counter readback
 	uint32_t* host_counters;
 	// instrumentation
@@ -814,10 +837,13 @@ static int pt_build_bottom_up(pt_scene* s, const PtBuild& b, uint32_t* queues[2]
 
 static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 	uint32_t n = s->triangle_count;
-	hipEvent_t begin, end;
-	PT_CHECK(hipEventCreate(&begin));
-	PT_CHECK(hipEventCreate(&end));
-	PT_CHECK(hipEventRecord(begin, s->stream));
+	hipEvent_t begin = NULL, end = NULL;
+	if (hipEventCreate(&begin) != hipSuccess || hipEventCreate(&end) != hipSuccess || hipEventRecord(begin, s->stream) != hipSuccess) {
+		printf("Failed to create the events that time the BVH build.\n");
+		if (begin) hipEventDestroy(begin);
+		if (end) hipEventDestroy(end);
+		return 1;
+	}
 	PtBuild b;
 	memset(&b, 0, sizeof(b));
 	b.n = n;
@@ -932,7 +958,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 	return result;
 }
 
-extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const pt_scene_header_t* header,
+static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const pt_scene_header_t* header,
 	const uint32_t* positions, const uint16_t* normals_and_tex_coords, const uint8_t* material_indices,
 	const pt_texture_desc_t* textures, uint32_t texture_count)
 {
@@ -964,11 +990,22 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 			return 1;
 		}
 	}
+	// A material index beyond the table would send the shading kernels past the
+	// end of the texture table: such a file is refused here, not on the GPU
+	for (uint64_t i = 0; i != header->triangle_count; ++i) {
+		if (material_indices[i] >= header->material_count) {
+			printf("Triangle %llu uses material %u but the scene has %llu materials.\n", (unsigned long long) i, (uint32_t) material_indices[i], (unsigned long long) header->material_count);
+			return 1;
+		}
+	}
 	if (hipSetDevice(device_index) != hipSuccess) {
 		printf("Failed to select GPU %d.\n", device_index);
 		return 1;
 	}
 	pt_scene* s = new pt_scene();
+	// From here on the caller's pointer owns the scene: whoever sees this
+	// function fail or throw destroys it
+	*out_scene = s;
 	s->device = device_index;
 	s->stream = NULL;
 	s->triangle_count = (uint32_t) header->triangle_count;
@@ -987,7 +1024,7 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 	s->accum = NULL;
 	s->sample_count = 0;
 	memset(&s->wf, 0, sizeof(s->wf));
-	s->counters = NULL; s->constants = NULL; s->stack_overflow = NULL; s->stack_overflow_shadow = NULL; s->shadow_stream = NULL; s->shade_done = NULL; s->shadow_done = NULL; s->visit_counters = NULL; s->host_counters = NULL;
+	s->counters = NULL; s->constants = NULL; s->stack_overflow = NULL; s->stack_overflow_shadow = NULL; s->shadow_stream = NULL; s->shade_done = NULL; s->shadow_done = NULL; s->visit_counters = NULL; s->error_word = NULL; s->host_counters = NULL;
 	s->stack_capacity = s->stack_overflow_stride = s->trace_grid = 0;
 	s->timing_enabled = s->visit_counters_enabled = 0;
 	memset(&s->stats, 0, sizeof(s->stats));
@@ -999,7 +1036,9 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 		uint64_t n = s->triangle_count;
 		if (pt_alloc(&s->positions, 3 * n) || pt_alloc(&s->normals_uvs, 3 * n) || pt_alloc(&s->shade_tris, n) || pt_alloc(&s->materials, n)
 			|| pt_alloc(&s->counters, PT_COUNTER_WORDS + PT_FETCH_WORDS) || pt_alloc(&s->constants, 1) || pt_alloc(&s->visit_counters, PT_VISIT_COUNTERS)
-			|| pt_alloc(&s->srgb_to_linear, 256) || pt_alloc(&s->lights, 1))
+			|| pt_alloc(&s->srgb_to_linear, 256) || pt_alloc(&s->lights, 1) || pt_alloc(&s->error_word, 1))
+			break;
+		if (hipMemsetAsync(s->error_word, 0, sizeof(uint32_t), s->stream) != hipSuccess)
 			break;
 		if (n) {
 			if (hipMemcpyAsync(s->positions, positions, n * 24, hipMemcpyHostToDevice, s->stream) != hipSuccess
@@ -1082,9 +1121,9 @@ extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const p
 	if (failed) {
 		printf("Failed to create the scene on GPU %d.\n", device_index);
 		pt_destroy_scene(s);
+		*out_scene = NULL;
 		return 1;
 	}
-	*out_scene = s;
 	return 0;
 }
 
@@ -1096,7 +1135,13 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 		hipStreamSynchronize(s->shadow_stream);
 	if (s->stream)
 		hipStreamSynchronize(s->stream);
-	pt_collect(s);
+	pt_guarded("pt_destroy_scene", [&]() { pt_collect(s); return 0; });
+	for (size_t i = 0; i != s->pending_events.size(); ++i) {
+		hipEventDestroy(s->pending_events[i].begin);
+		hipEventDestroy(s->pending_events[i].end);
+	}
+	for (size_t i = 0; i != s->pending_counter_reads.size(); ++i)
+		hipHostFree(s->pending_counter_reads[i].counters);
 	for (size_t i = 0; i != s->event_pool.size(); ++i)
 		hipEventDestroy(s->event_pool[i]);
 	for (size_t i = 0; i != s->snapshot_pool.size(); ++i)
@@ -1104,7 +1149,7 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 	pt_free_render_targets(s);
 	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->shade_tris); hipFree(s->materials); hipFree(s->texture_table); hipFree(s->texture_blob);
 	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->light_nodes); hipFree(s->tree_lights); hipFree(s->nodes); hipFree(s->tris);
-	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters); hipFree(s->stack_overflow); hipFree(s->stack_overflow_shadow);
+	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters); hipFree(s->error_word); hipFree(s->stack_overflow); hipFree(s->stack_overflow_shadow);
 	if (s->shade_done) hipEventDestroy(s->shade_done);
 	if (s->shadow_done) hipEventDestroy(s->shadow_done);
 	if (s->shadow_stream)
@@ -1114,7 +1159,7 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 	delete s;
 }
 
-extern "C" int pt_set_lights(pt_scene_t* s, const float* lights, uint32_t count) {
+static int pt_set_lights_impl(pt_scene_t* s, const float* lights, uint32_t count) {
 	if (!s || (count && !lights))
 		return 1;
 	PT_CHECK(hipSetDevice(s->device));
@@ -1168,7 +1213,7 @@ extern "C" int pt_set_render_settings(pt_scene_t* s, int sampling_strategy, uint
 	return 0;
 }
 
-extern "C" int pt_create_render_targets(pt_scene_t* s, uint32_t width, uint32_t height) {
+static int pt_create_render_targets_impl(pt_scene_t* s, uint32_t width, uint32_t height) {
 	if (!s)
 		return 1;
 	if (width == 0 || height == 0 || (uint64_t) width * height > (1ull << 28)) {
@@ -1193,9 +1238,13 @@ extern "C" int pt_create_render_targets(pt_scene_t* s, uint32_t width, uint32_t 
 	uint64_t target_paths = PT_BATCH_TARGET_PATHS;
 	if (const char* override = getenv("PT_BATCH_PATHS"))
 		target_paths = strtoull(override, NULL, 10);
-	s->max_frames_per_batch = (uint32_t) ((target_paths + l.paths_per_frame - 1) / l.paths_per_frame);
-	if (s->max_frames_per_batch < 1) s->max_frames_per_batch = 1;
-	if (s->max_frames_per_batch > 64) s->max_frames_per_batch = 64;
+	// Path and slot indices are 32-bit: a batch stays below 2^31 paths whatever the override says
+	uint64_t frames = (target_paths + l.paths_per_frame - 1) / l.paths_per_frame;
+	const uint64_t frame_limit = (1ull << 31) / l.paths_per_frame;
+	if (frames > frame_limit) frames = frame_limit;
+	if (frames > 64) frames = 64;
+	if (frames < 1) frames = 1;
+	s->max_frames_per_batch = (uint32_t) frames;
 	if (pt_alloc(&s->accum, (uint64_t) width * height)) {
 		pt_free_render_targets(s);
 		return 1;
@@ -1218,6 +1267,7 @@ static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity, 
 	a.cache_layout = pt_cache_layout(s->bvh_info.node_count, s->bvh_info.triangle_count);
 	a.fetch = s->counters + PT_COUNTER_WORDS + 8 * PT_FETCH_STRIDE * (shadow ? PT_SHADOW_COUNT_OFFSET + bounce : bounce);
 	a.visit_counters = s->visit_counters_enabled ? s->visit_counters : NULL;
+	a.error_word = s->error_word;
 	return a;
 }
 
@@ -1327,7 +1377,7 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 	return 0;
 }
 
-extern "C" int pt_render_samples(pt_scene_t* s, const pt_constants_t* constants,
+static int pt_render_samples_impl(pt_scene_t* s, const pt_constants_t* constants,
 	uint32_t first_frame_index, uint32_t sample_count, uint32_t frame_stride, int accumulate)
 {
 	if (!s || !constants)
@@ -1346,11 +1396,6 @@ extern "C" int pt_render_samples(pt_scene_t* s, const pt_constants_t* constants,
 	uint32_t frames_per_batch = s->max_frames_per_batch < sample_count ? s->max_frames_per_batch : sample_count;
 	if (pt_reserve_wavefront(s, s->frame_layout.paths_per_frame * frames_per_batch))
 		return 1;
-	// Keep the backlog of events and snapshots bounded
-	if (s->pending_counter_reads.size() > 256) {
-		PT_CHECK(hipStreamSynchronize(s->stream));
-		pt_collect(s);
-	}
 	PT_CHECK(hipMemcpyAsync(s->constants, constants, sizeof(PtConstants), hipMemcpyHostToDevice, s->stream));
 	if (!accumulate)
 		s->sample_count = 0;
@@ -1360,6 +1405,12 @@ extern "C" int pt_render_samples(pt_scene_t* s, const pt_constants_t* constants,
 		if (frames > frames_per_batch)
 			frames = frames_per_batch;
 		int overwrite_first = (!accumulate && done == 0) ? 1 : 0;
+		// Keep the backlog of events and counter snapshots bounded, however
+		// many batches one call renders
+		if (s->pending_counter_reads.size() > 256 || s->pending_events.size() > 4096) {
+			PT_CHECK(hipStreamSynchronize(s->stream));
+			pt_collect(s);
+		}
 		if (pt_render_batch(s, first_frame_index + done * frame_stride, frames, frame_stride, overwrite_first))
 			return 1;
 		done += frames;
@@ -1368,19 +1419,34 @@ extern "C" int pt_render_samples(pt_scene_t* s, const pt_constants_t* constants,
 	return 0;
 }
 
-extern "C" int pt_synchronize(pt_scene_t* s) {
+// Reads the error word that the traversal kernels set when they had to give
+// up on rays; the stream must be idle. The word is cleared once reported.
+static int pt_check_device_errors(pt_scene* s) {
+	uint32_t errors = 0;
+	PT_CHECK(hipMemcpy(&errors, s->error_word, sizeof(errors), hipMemcpyDeviceToHost));
+	if (errors == 0)
+		return 0;
+	if (errors & PT_ERROR_STACK_OVERFLOW)
+		printf("The BVH traversal ran out of stack (%u entries per ray): some rays did not get their closest hit.\n", s->stack_capacity);
+	if (errors & PT_ERROR_PASS_LIMIT)
+		printf("The BVH traversal stopped at its pass limit before all rays were done.\n");
+	PT_CHECK(hipMemset(s->error_word, 0, sizeof(errors)));
+	return 1;
+}
+
+static int pt_synchronize_impl(pt_scene_t* s) {
 	if (!s)
 		return 1;
 	PT_CHECK(hipSetDevice(s->device));
 	PT_CHECK(hipStreamSynchronize(s->stream));
 	pt_collect(s);
-	return 0;
+	return pt_check_device_errors(s);
 }
 
-extern "C" int pt_read_accumulation(pt_scene_t* s, float* rgba, uint32_t* out_sample_count) {
+static int pt_read_accumulation_impl(pt_scene_t* s, float* rgba, uint32_t* out_sample_count) {
 	if (!s)
 		return 1;
-	if (pt_synchronize(s))
+	if (pt_synchronize_impl(s))
 		return 1;
 	if (rgba) {
 		if (!s->accum) {
@@ -1403,20 +1469,20 @@ extern "C" int pt_set_sample_count(pt_scene_t* s, uint32_t sample_count) {
 	return 0;
 }
 
-extern "C" int pt_set_instrumentation(pt_scene_t* s, int enable_kernel_timing, int enable_visit_counters) {
+static int pt_set_instrumentation_impl(pt_scene_t* s, int enable_kernel_timing, int enable_visit_counters) {
 	if (!s)
 		return 1;
-	if (pt_synchronize(s))
+	if (pt_synchronize_impl(s))
 		return 1;
 	s->timing_enabled = enable_kernel_timing;
 	s->visit_counters_enabled = enable_visit_counters;
 	return 0;
 }
 
-extern "C" int pt_get_statistics(pt_scene_t* s, pt_statistics_t* out) {
+static int pt_get_statistics_impl(pt_scene_t* s, pt_statistics_t* out) {
 	if (!s || !out)
 		return 1;
-	if (pt_synchronize(s))
+	if (pt_synchronize_impl(s))
 		return 1;
 	unsigned long long visits[PT_VISIT_COUNTERS];
 	PT_CHECK(hipMemcpy(visits, s->visit_counters, sizeof(visits), hipMemcpyDeviceToHost));
@@ -1434,10 +1500,10 @@ extern "C" int pt_get_statistics(pt_scene_t* s, pt_statistics_t* out) {
 	return 0;
 }
 
-extern "C" int pt_reset_statistics(pt_scene_t* s) {
+static int pt_reset_statistics_impl(pt_scene_t* s) {
 	if (!s)
 		return 1;
-	if (pt_synchronize(s))
+	if (pt_synchronize_impl(s))
 		return 1;
 	memset(&s->stats, 0, sizeof(s->stats));
 	PT_CHECK(hipMemset(s->visit_counters, 0, PT_VISIT_COUNTERS * sizeof(unsigned long long)));
@@ -1451,7 +1517,7 @@ extern "C" int pt_get_bvh_info(pt_scene_t* s, pt_bvh_info_t* out) {
 	return 0;
 }
 
-extern "C" int pt_trace_primary_rays(pt_scene_t* s, const pt_constants_t* constants, uint32_t frame_index,
+static int pt_trace_primary_rays_impl(pt_scene_t* s, const pt_constants_t* constants, uint32_t frame_index,
 	int32_t* triangle_indices, float* barycentrics, uint8_t* front)
 {
 	if (!s || !constants || !triangle_indices || !barycentrics || !front)
@@ -1493,12 +1559,14 @@ extern "C" int pt_trace_primary_rays(pt_scene_t* s, const pt_constants_t* consta
 		result = 0;
 	} while (0);
 	hipFree(d_triangles); hipFree(d_barycentrics); hipFree(d_front);
+	if (!result)
+		result = pt_check_device_errors(s);
 	if (result)
 		printf("Failed to trace primary rays on the GPU.\n");
 	return result;
 }
 
-extern "C" int pt_trace_rays(pt_scene_t* s, const float* origins, const float* directions, uint32_t ray_count,
+static int pt_trace_rays_impl(pt_scene_t* s, const float* origins, const float* directions, uint32_t ray_count,
 	int32_t* triangle_indices, float* t_u_v, uint8_t* front)
 {
 	if (!s || (ray_count && (!origins || !directions || !triangle_indices || !t_u_v || !front)))
@@ -1536,6 +1604,7 @@ extern "C" int pt_trace_rays(pt_scene_t* s, const float* origins, const float* d
 		a.stack_overflow_stride = s->stack_overflow_stride;
 		a.stack_capacity = s->stack_capacity;
 		a.cache_layout = pt_cache_layout(s->bvh_info.node_count, s->bvh_info.triangle_count);
+		a.error_word = s->error_word;
 		a.triangles = d_triangles;
 		a.t_u_v = d_tuv;
 		a.front = d_front;
@@ -1548,12 +1617,14 @@ extern "C" int pt_trace_rays(pt_scene_t* s, const float* origins, const float* d
 		result = 0;
 	} while (0);
 	hipFree(d_origins); hipFree(d_directions); hipFree(d_triangles); hipFree(d_tuv); hipFree(d_front); hipFree(d_control);
+	if (!result)
+		result = pt_check_device_errors(s);
 	if (result)
 		printf("Failed to trace %u rays on the GPU.\n", ray_count);
 	return result;
 }
 
-extern "C" int pt_evaluate_shading_data(pt_scene_t* s, const pt_constants_t* constants,
+static int pt_evaluate_shading_data_impl(pt_scene_t* s, const pt_constants_t* constants,
 	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs,
 	uint32_t count, float* out_shading_data)
 {
@@ -1609,4 +1680,66 @@ extern "C" int pt_random_numbers(int device_index, uint32_t x, uint32_t y, uint3
 		return 1;
 	}
 	return 0;
+}
+
+
+// ---------------------------------------------------------------- C ABI
+// The entry points proper: each runs its implementation above under
+// pt_guarded(), so that no C++ exception reaches the C caller.
+
+extern "C" int pt_create_scene(pt_scene_t** out_scene, int device_index, const pt_scene_header_t* header,
+	const uint32_t* positions, const uint16_t* normals_and_tex_coords, const uint8_t* material_indices,
+	const pt_texture_desc_t* textures, uint32_t texture_count)
+{
+	int result = pt_guarded("pt_create_scene", [&]() { return pt_create_scene_impl(out_scene, device_index, header, positions, normals_and_tex_coords, material_indices, textures, texture_count); });
+	if (result && out_scene && *out_scene) {
+		// An exception left a partially built scene behind
+		pt_destroy_scene(*out_scene);
+		*out_scene = NULL;
+	}
+	return result;
+}
+
+extern "C" int pt_set_lights(pt_scene_t* scene, const float* lights, uint32_t count) {
+	return pt_guarded("pt_set_lights", [&]() { return pt_set_lights_impl(scene, lights, count); });
+}
+
+extern "C" int pt_create_render_targets(pt_scene_t* scene, uint32_t width, uint32_t height) {
+	return pt_guarded("pt_create_render_targets", [&]() { return pt_create_render_targets_impl(scene, width, height); });
+}
+
+extern "C" int pt_render_samples(pt_scene_t* scene, const pt_constants_t* constants, uint32_t first_frame_index, uint32_t sample_count, uint32_t frame_stride, int accumulate) {
+	return pt_guarded("pt_render_samples", [&]() { return pt_render_samples_impl(scene, constants, first_frame_index, sample_count, frame_stride, accumulate); });
+}
+
+extern "C" int pt_synchronize(pt_scene_t* scene) {
+	return pt_guarded("pt_synchronize", [&]() { return pt_synchronize_impl(scene); });
+}
+
+extern "C" int pt_read_accumulation(pt_scene_t* scene, float* rgba, uint32_t* out_sample_count) {
+	return pt_guarded("pt_read_accumulation", [&]() { return pt_read_accumulation_impl(scene, rgba, out_sample_count); });
+}
+
+extern "C" int pt_set_instrumentation(pt_scene_t* scene, int enable_kernel_timing, int enable_visit_counters) {
+	return pt_guarded("pt_set_instrumentation", [&]() { return pt_set_instrumentation_impl(scene, enable_kernel_timing, enable_visit_counters); });
+}
+
+extern "C" int pt_get_statistics(pt_scene_t* scene, pt_statistics_t* out_statistics) {
+	return pt_guarded("pt_get_statistics", [&]() { return pt_get_statistics_impl(scene, out_statistics); });
+}
+
+extern "C" int pt_reset_statistics(pt_scene_t* scene) {
+	return pt_guarded("pt_reset_statistics", [&]() { return pt_reset_statistics_impl(scene); });
+}
+
+extern "C" int pt_trace_primary_rays(pt_scene_t* scene, const pt_constants_t* constants, uint32_t frame_index, int32_t* triangle_indices, float* barycentrics, uint8_t* front) {
+	return pt_guarded("pt_trace_primary_rays", [&]() { return pt_trace_primary_rays_impl(scene, constants, frame_index, triangle_indices, barycentrics, front); });
+}
+
+extern "C" int pt_trace_rays(pt_scene_t* scene, const float* origins, const float* directions, uint32_t ray_count, int32_t* triangle_indices, float* t_u_v, uint8_t* front) {
+	return pt_guarded("pt_trace_rays", [&]() { return pt_trace_rays_impl(scene, origins, directions, ray_count, triangle_indices, t_u_v, front); });
+}
+
+extern "C" int pt_evaluate_shading_data(pt_scene_t* scene, const pt_constants_t* constants, const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out_shading_data) {
+	return pt_guarded("pt_evaluate_shading_data", [&]() { return pt_evaluate_shading_data_impl(scene, constants, triangle_indices, barycentrics, front, out_dirs, count, out_shading_data); });
 }

@@ -56,6 +56,10 @@
 #define PT_TRIS_PER_PASS 1   // triangle tests per lane and pass
 #endif
 
+// Bits of the error word that the traversal sets when it had to give up on rays
+#define PT_ERROR_STACK_OVERFLOW 1u // a traversal stack deeper than stack_capacity entries
+#define PT_ERROR_PASS_LIMIT 2u     // a wave ran into the bound on its passes
+
 struct PtWaveLds {
 	u32x2 stack[PT_WAVE_STACK][64];
 };
@@ -123,7 +127,7 @@ __device__ __forceinline__ uint32_t pt_lane() { return __builtin_amdgcn_mbcnt_hi
 template <bool COUNT_VISITS, typename Finish>
 __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache, const PtCacheLayout layout, const PtNode* __restrict__ nodes, const PtTri* __restrict__ tris, uint32_t triangle_count,
 	const PtRayQueue& queue, u32x2* stack_overflow, uint32_t stack_overflow_stride, uint32_t stack_capacity,
-	unsigned long long* visit_counters, Finish finish)
+	unsigned long long* visit_counters, uint32_t* error_word, Finish finish)
 {
 	const uint32_t lane = pt_lane();
 	const uint32_t ray_total = *queue.count;
@@ -167,7 +171,10 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 
 	// Every pass retires, fetches, walks or tests something, so the loop ends
 	// when the queue is used up; the bound only guards the GPU against a logic
-	// error ever hanging it.
+	// error ever hanging it. Running into it, or into the end of the stack,
+	// would leave rays without their closest hit: both set a bit of the error
+	// word, which the host checks when it waits for the work.
+	bool drained = false;
 	for (uint32_t pass = 0; pass != (1u << 26); ++pass) {
 		// ---- refill idle lanes ----
 		unsigned long long idle_mask = __ballot(!active);
@@ -242,8 +249,10 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			}
 		}
 		// ---- exit: nothing in flight and nothing left to fetch ----
-		if (!rays_remain && __ballot(active) == 0)
+		if (!rays_remain && __ballot(active) == 0) {
+			drained = true;
 			break;
+		}
 
 		if (COUNT_VISITS)
 			node_pass_count += __ballot(active && (tgroup.y & 0xffu) == 0) != 0;
@@ -272,6 +281,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 						*(pt_global_vec2*) &stack_overflow[(uint64_t) (sp - PT_WAVE_STACK) * stack_overflow_stride] = entry;
 					if (sp < stack_capacity)
 						++sp;
+					else
+						atomicOr(error_word, PT_ERROR_STACK_OVERFLOW);
 				}
 				uint32_t child_slot = (bit - 24u) ^ octinv;
 				uint32_t rel = (uint32_t) __builtin_popcount(ngroup.y & 0xffu & ((1u << child_slot) - 1u));
@@ -357,6 +368,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			active = false;
 		}
 	}
+	if (!drained && lane == 0)
+		atomicOr(error_word, PT_ERROR_PASS_LIMIT);
 	if (COUNT_VISITS) {
 		atomicAdd(&visit_counters[0], (unsigned long long) node_visits);
 		atomicAdd(&visit_counters[1], (unsigned long long) tri_visits);

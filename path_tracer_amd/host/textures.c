@@ -44,12 +44,27 @@ static int init_texture(texture_t* texture, const char* texture_file_path) {
 		for (uint32_t i = 0; i != texture->mipmap_count; ++i) {
 			uint32_t mip_extent[2];
 			if (fread(mip_extent, sizeof(uint32_t), 2, file) != 2 || fread(&texture->mipmap_sizes[i], sizeof(uint64_t), 1, file) != 1
-				|| fread(&offsets[i], sizeof(uint64_t), 1, file) != 1 || offsets[i] + texture->mipmap_sizes[i] > payload_size)
+				|| fread(&offsets[i], sizeof(uint64_t), 1, file) != 1
+				/* written so that no sum can wrap around */
+				|| offsets[i] > payload_size || texture->mipmap_sizes[i] > payload_size - offsets[i])
 				headers_ok = false;
 		}
-		texture->payload = malloc(payload_size ? payload_size : 1);
+		/* The payload cannot be larger than what is left of the file */
+		long payload_begin = ftell(file);
+		uint64_t bytes_left = 0;
+		if (payload_begin >= 0 && fseek(file, 0, SEEK_END) == 0) {
+			long file_end = ftell(file);
+			if (file_end >= payload_begin)
+				bytes_left = (uint64_t) (file_end - payload_begin);
+			if (fseek(file, payload_begin, SEEK_SET) != 0)
+				bytes_left = 0;
+		}
+		if (payload_size > bytes_left)
+			headers_ok = false;
+		if (headers_ok)
+			texture->payload = malloc(payload_size ? payload_size : 1);
 		uint32_t eof_marker = 0;
-		if (!headers_ok || fread(texture->payload, 1, payload_size, file) != payload_size
+		if (!headers_ok || !texture->payload || fread(texture->payload, 1, payload_size, file) != payload_size
 			|| fread(&eof_marker, sizeof(eof_marker), 1, file) != 1 || eof_marker != 0xe0fe0f)
 		{
 			printf("The texture file at %s is truncated or its mipmap headers are inconsistent.\n", texture_file_path);

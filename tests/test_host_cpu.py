@@ -265,3 +265,48 @@ def test_slides_table():
     assert host_api.lib().run_slideshow(C.byref(show), 0, b".", b".", 64, 64, 0, 1) != 0  # past the end: refused before any GPU work
     host_api.lib().free_slideshow(C.byref(show))
     assert show.slide_count == 0
+
+
+def test_scene_with_material_index_out_of_range_is_refused():
+    """A triangle whose material index lies beyond the material table must make pt_create_scene() return
+    nonzero before anything reaches the GPU (the check runs on the host, so it is testable without one)."""
+    from tests import synthetic
+    scene = synthetic.triangle_soup(seed=3, triangle_count=50, material_count=2)
+    textures = [(t.width, t.height, t.format, [t.payload[int(t.mip_offsets[m]):int(t.mip_offsets[m]) + t.mip_extents[m][2]] for m in range(t.mip_count)])
+                for t in scene.textures]
+    materials = scene.materials.copy()
+    materials[17] = 2
+    with pytest.raises(hip_api.PtError):
+        hip_api.Scene(2, scene.dequantization_factor, scene.dequantization_summand, scene.positions, scene.normals_uvs, materials, textures)
+    # Triangles but no materials at all
+    with pytest.raises(hip_api.PtError):
+        hip_api.Scene(0, scene.dequantization_factor, scene.dequantization_summand, scene.positions, scene.normals_uvs, scene.materials, [])
+
+
+def test_texture_file_with_wrapping_mip_header_is_refused(tmp_path):
+    """offset + size of a mip header that wraps around 2^64 must not pass the bounds check of the loader, nor may a
+    payload size beyond the end of the file."""
+    import struct
+    source = open(os.path.join(DATA, "cornell_box_textures", "white_BaseColor.vkt"), "rb").read()
+    marker, version, mips, width, height, fmt, payload = struct.unpack_from("<IIIIIIQ", source, 0)
+    assert marker == 0xbc1bc1 and mips >= 1
+    library = host_api.lib()
+
+    def loads(blob):
+        path = tmp_path / "t.vkt"
+        path.write_bytes(blob)
+        textures = host_api.HostTextures()
+        paths = (C.c_char_p * 1)(str(path).encode())
+        code = library.load_textures(C.byref(textures), paths, 1)
+        if code == 0:
+            library.free_textures(C.byref(textures))
+        return code == 0
+
+    assert loads(source)
+    # first mip header: u32 w, u32 h, u64 size, u64 offset at byte 32
+    wrapped = bytearray(source)
+    struct.pack_into("<QQ", wrapped, 32 + 8, 16, 2 ** 64 - 8)
+    assert not loads(bytes(wrapped))
+    huge = bytearray(source)
+    struct.pack_into("<Q", huge, 24, 2 ** 40)
+    assert not loads(bytes(huge))

@@ -192,6 +192,21 @@ int pt_trace_primary_rays(pt_scene_t* scene, const pt_constants_t* constants, ui
 int pt_trace_rays(pt_scene_t* scene, const float* origins, const float* directions, uint32_t ray_count,
 	int32_t* triangle_indices, float* t_u_v, uint8_t* front);
 
+/* pt_trace_rays() without any allocation. It has no counterpart in the
+ * reference; it is for callers that cannot allocate device memory: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * All five arrays are device memory of the caller on the scene's GPU
+ * (origins and directions three floats per ray, results as pt_trace_rays()
+ * returns them). The ray queue and its counters live in an array that is
+ * part of the library's code object (33 MiB per GPU, held until the process
+ * ends), hence at most 1048576 rays per call; more are refused with a
+ * message. Calls on one GPU share that array: calls that overlap in time on
+ * one GPU, from whatever scene or thread, race. Returns when the results are
+ * complete. */
+#define PT_TRACE_RAYS_NO_ALLOC_MAX_RAYS 1048576u
+int pt_trace_rays_no_alloc(pt_scene_t* scene, const float* device_origins, const float* device_directions, uint32_t ray_count,
+	int32_t* device_triangle_indices, float* device_t_u_v, uint8_t* device_front);
+
 /* Test hook: get_shading_data() of src/shaders/shading_data.glsl:51-103 for
  * given hits; 20 floats per hit in the member order of shading_data_t. */
 int pt_evaluate_shading_data(pt_scene_t* scene, const pt_constants_t* constants,

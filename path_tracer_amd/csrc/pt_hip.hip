@@ -558,6 +558,31 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_user_rays(PtUserRayArg
 		});
 }
 
+// Scratch memory of pt_trace_rays_no_alloc(): a control block (the ray count
+// and the eight fetch counters of the traversal, 4096 bytes) followed by the
+// staged origins and directions as the traversal reads them (two f32x4 per
+// ray). It is part of the code object, so no call has to allocate it; every
+// GPU that the library runs on holds its own copy until the process ends.
+// In host code this name only stands for the symbol: the array's address on a
+// device comes from hipGetSymbolAddress() (pt_no_alloc_scratch_address()).
+#define PT_NO_ALLOC_MAX_RAYS PT_TRACE_RAYS_NO_ALLOC_MAX_RAYS
+#define PT_NO_ALLOC_CONTROL_BYTES 4096u
+static_assert(sizeof(uint32_t) * (1 + 8 * PT_FETCH_STRIDE) <= PT_NO_ALLOC_CONTROL_BYTES, "control block too small");
+static __device__ __align__(256) unsigned char pt_no_alloc_scratch[PT_NO_ALLOC_CONTROL_BYTES + 2ull * sizeof(f32x4) * PT_NO_ALLOC_MAX_RAYS];
+
+// Brings caller-supplied rays (three floats per origin and direction) into the
+// layout of a ray queue and publishes their number; control[1...] must have
+// been zeroed before
+__global__ void __launch_bounds__(PT_BLOCK) k_stage_user_rays(const float* origins, const float* directions, uint32_t ray_count, uint32_t* control, f32x4* staged_origins, f32x4* staged_directions) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i == 0)
+		control[0] = ray_count;
+	if (i >= ray_count)
+		return;
+	staged_origins[i] = mk4(origins[3 * (uint64_t) i], origins[3 * (uint64_t) i + 1], origins[3 * (uint64_t) i + 2], pt_as_float(i));
+	staged_directions[i] = mk4(directions[3 * (uint64_t) i], directions[3 * (uint64_t) i + 1], directions[3 * (uint64_t) i + 2], 0.0f);
+}
+
 __global__ void __launch_bounds__(PT_BLOCK) k_shading_data(PtSceneView scene, const PtConstants* constants, const int32_t* triangles, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out) {
 	pt_stage_srgb_table(scene.srgb_to_linear);
 	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
@@ -635,6 +660,7 @@ struct pt_scene {
 	hipEvent_t shade_done, shadow_done;
 	unsigned long long* visit_counters;
 	uint32_t* error_word; // device word of PT_ERROR_* bits
+	unsigned char* no_alloc_scratch; // this device's copy of pt_no_alloc_scratch
 	// pinned host staging for counter readback
 	uint32_t* host_counters;
 	// instrumentation
@@ -958,6 +984,26 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 	return result;
 }
 
+// The address of pt_no_alloc_scratch on each device, looked up once per
+// device (by pt_create_scene(), with that device current)
+#define PT_MAX_DEVICES 64
+static void* pt_no_alloc_scratch_addresses[PT_MAX_DEVICES];
+
+static int pt_no_alloc_scratch_address(int device_index, void** out_address) {
+	*out_address = NULL;
+	if (device_index < 0 || device_index >= PT_MAX_DEVICES) {
+		printf("GPU index %d is beyond the %d devices that the library keeps scratch addresses for.\n", device_index, PT_MAX_DEVICES);
+		return 1;
+	}
+	if (!pt_no_alloc_scratch_addresses[device_index]) {
+		void* address = NULL;
+		PT_CHECK(hipGetSymbolAddress(&address, HIP_SYMBOL(pt_no_alloc_scratch)));
+		pt_no_alloc_scratch_addresses[device_index] = address;
+	}
+	*out_address = pt_no_alloc_scratch_addresses[device_index];
+	return 0;
+}
+
 static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const pt_scene_header_t* header,
 	const uint32_t* positions, const uint16_t* normals_and_tex_coords, const uint8_t* material_indices,
 	const pt_texture_desc_t* textures, uint32_t texture_count)
@@ -1002,7 +1048,12 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 		printf("Failed to select GPU %d.\n", device_index);
 		return 1;
 	}
+	// Set-up for pt_trace_rays_no_alloc(): where this device keeps the scratch array
+	void* no_alloc_scratch = NULL;
+	if (pt_no_alloc_scratch_address(device_index, &no_alloc_scratch))
+		return 1;
 	pt_scene* s = new pt_scene();
+	s->no_alloc_scratch = (unsigned char*) no_alloc_scratch;
 	// From here on the caller's pointer owns the scene: whoever sees this
 	// function fail or throw destroys it
 	*out_scene = s;
@@ -1624,6 +1675,50 @@ static int pt_trace_rays_impl(pt_scene_t* s, const float* origins, const float* 
 	return result;
 }
 
+// pt_trace_rays() for callers that cannot allocate: inputs and outputs are
+// device memory of the caller, the ray queue and its counters live in the
+// scratch array of the code object. No hipMalloc, hipFree, std::vector or
+// other allocating routine is called on this path.
+static int pt_trace_rays_no_alloc_impl(pt_scene_t* s, const float* device_origins, const float* device_directions, uint32_t ray_count,
+	int32_t* device_triangle_indices, float* device_t_u_v, uint8_t* device_front)
+{
+	if (!s || (ray_count && (!device_origins || !device_directions || !device_triangle_indices || !device_t_u_v || !device_front)))
+		return 1;
+	if (ray_count > PT_NO_ALLOC_MAX_RAYS) {
+		printf("pt_trace_rays_no_alloc() takes at most %u rays per call, got %u.\n", PT_NO_ALLOC_MAX_RAYS, ray_count);
+		return 1;
+	}
+	if (ray_count == 0)
+		return 0;
+	PT_CHECK(hipSetDevice(s->device));
+	// The address that hipGetSymbolAddress() returned for this device, never the array's name
+	unsigned char* scratch = s->no_alloc_scratch;
+	uint32_t* control = (uint32_t*) scratch;
+	f32x4* staged_origins = (f32x4*) (scratch + PT_NO_ALLOC_CONTROL_BYTES);
+	f32x4* staged_directions = staged_origins + PT_NO_ALLOC_MAX_RAYS;
+	// The array keeps what the previous call left: the counters must start at zero
+	PT_CHECK(hipMemsetAsync(control, 0, PT_NO_ALLOC_CONTROL_BYTES, s->stream));
+	hipLaunchKernelGGL(k_stage_user_rays, dim3(pt_grid(ray_count)), dim3(PT_BLOCK), 0, s->stream, device_origins, device_directions, ray_count, control, staged_origins, staged_directions);
+	PtUserRayArgs a;
+	a.scene = pt_scene_view(s);
+	a.origins = staged_origins;
+	a.directions = staged_directions;
+	a.count = control;
+	a.fetch = control + 1;
+	a.stack_overflow = s->stack_overflow;
+	a.stack_overflow_stride = s->stack_overflow_stride;
+	a.stack_capacity = s->stack_capacity;
+	a.cache_layout = pt_cache_layout(s->bvh_info.node_count, s->bvh_info.triangle_count);
+	a.error_word = s->error_word;
+	a.triangles = device_triangle_indices;
+	a.t_u_v = device_t_u_v;
+	a.front = device_front;
+	hipLaunchKernelGGL(k_trace_user_rays, dim3(pt_trace_grid(s, ray_count)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+	PT_CHECK(hipGetLastError());
+	PT_CHECK(hipStreamSynchronize(s->stream));
+	return pt_check_device_errors(s);
+}
+
 static int pt_evaluate_shading_data_impl(pt_scene_t* s, const pt_constants_t* constants,
 	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs,
 	uint32_t count, float* out_shading_data)
@@ -1742,4 +1837,8 @@ extern "C" int pt_trace_rays(pt_scene_t* scene, const float* origins, const floa
 
 extern "C" int pt_evaluate_shading_data(pt_scene_t* scene, const pt_constants_t* constants, const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out_shading_data) {
 	return pt_guarded("pt_evaluate_shading_data", [&]() { return pt_evaluate_shading_data_impl(scene, constants, triangle_indices, barycentrics, front, out_dirs, count, out_shading_data); });
+}
+
+extern "C" int pt_trace_rays_no_alloc(pt_scene_t* scene, const float* device_origins, const float* device_directions, uint32_t ray_count, int32_t* device_triangle_indices, float* device_t_u_v, uint8_t* device_front) {
+	return pt_guarded("pt_trace_rays_no_alloc", [&]() { return pt_trace_rays_no_alloc_impl(scene, device_origins, device_directions, ray_count, device_triangle_indices, device_t_u_v, device_front); });
 }

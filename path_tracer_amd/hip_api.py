@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "pt_create_scene", "pt_destroy_scene", "pt_set_lights", "pt_set_light_sampling", "pt_set_render_settings", "pt_create_render_targets",
     "pt_render_samples", "pt_synchronize", "pt_read_accumulation", "pt_get_accumulation_device_pointer",
     "pt_set_sample_count", "pt_set_instrumentation", "pt_get_statistics", "pt_reset_statistics", "pt_get_bvh_info",
-    "pt_trace_primary_rays", "pt_trace_rays", "pt_evaluate_shading_data", "pt_random_numbers",
+    "pt_trace_primary_rays", "pt_trace_rays", "pt_trace_rays_no_alloc", "pt_evaluate_shading_data", "pt_random_numbers",
 ]
 
 
@@ -96,6 +96,7 @@ def lib():
         _lib.pt_get_bvh_info.argtypes = [vp, C.POINTER(BvhInfo)]
         _lib.pt_trace_primary_rays.argtypes = [vp, C.POINTER(Constants), u32, vp, vp, vp]
         _lib.pt_trace_rays.argtypes = [vp, vp, vp, u32, vp, vp, vp]
+        _lib.pt_trace_rays_no_alloc.argtypes = [vp, vp, vp, u32, vp, vp, vp]
         _lib.pt_evaluate_shading_data.argtypes = [vp, C.POINTER(Constants), vp, vp, vp, vp, u32, vp]
         _lib.pt_random_numbers.argtypes = [i32, u32, u32, u32, u32, vp]
     return _lib

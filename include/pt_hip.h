@@ -57,7 +57,11 @@ typedef struct {
 /* One texture as a .vkt file holds it (texture_header_t and mipmap_header_t
  * at src/textures.c:8-33): raw block-compressed mip levels. format is the
  * VkFormat number; 131 (BC1_RGB_UNORM), 132 (BC1_RGB_SRGB) and 141
- * (BC5_UNORM) are supported. Extents must be powers of two, at least 4. */
+ * (BC5_UNORM) are supported. Extents must be powers of two, at least 4.
+ * Mip level m has the extent (width >> m) x (height >> m) and levels end at an
+ * extent of 4, as the reference's converter writes them
+ * (tools/texture_conversion/main.c:283-293). All levels are used: lookups
+ * are trilinear, as the reference's sampler asks (src/main.c:864-873). */
 typedef struct {
 	uint32_t width, height;
 	uint32_t format;
@@ -208,9 +212,13 @@ int pt_trace_rays_no_alloc(pt_scene_t* scene, const float* device_origins, const
 	int32_t* device_triangle_indices, float* device_t_u_v, uint8_t* device_front);
 
 /* Test hook: get_shading_data() of src/shaders/shading_data.glsl:51-103 for
- * given hits; 20 floats per hit in the member order of shading_data_t. */
+ * given hits; 20 floats per hit in the member order of shading_data_t.
+ * footprints holds, per hit, the diameter of the path's footprint on the
+ * surface in scene units, from which the level of detail of the texture
+ * lookups follows (what the implicit derivatives of texture() are to the
+ * reference); NULL stands for zeros, i.e. mip level 0. */
 int pt_evaluate_shading_data(pt_scene_t* scene, const pt_constants_t* constants,
-	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs,
+	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, const float* footprints,
 	uint32_t count, float* out_shading_data);
 
 /* Test hook: the first draw_count pairs of get_random_numbers()

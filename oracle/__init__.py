@@ -67,8 +67,9 @@ def lib():
         _lib.oracle_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.oracle_rng_stream.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.oracle_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
-        _lib.oracle_shading_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
-        _lib.oracle_sample_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.oracle_shading_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.oracle_primary_cones.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        _lib.oracle_sample_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.oracle_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
         _lib.oracle_log.restype = C.c_float
         _lib.oracle_log.argtypes = [C.c_float]
@@ -124,6 +125,13 @@ class OracleScene:
                                                   emission_material_index, first_frame_index, frame_count, frame_stride, int(accumulate), _ptr(accum), threads)
         return accum, rays
 
+    def primary_cones(self, constants: Constants, frame_index):
+        width, height = int(constants.viewport_size[0]), int(constants.viewport_size[1])
+        widths = np.zeros((height, width), np.float32)
+        spreads = np.zeros((height, width), np.float32)
+        lib().oracle_primary_cones(C.byref(constants), frame_index, _ptr(widths), _ptr(spreads))
+        return widths, spreads
+
     def primary_hits(self, constants: Constants, frame_index):
         width, height = int(constants.viewport_size[0]), int(constants.viewport_size[1])
         triangles = np.zeros((height, width), np.int32)
@@ -142,7 +150,7 @@ class OracleScene:
         lib().oracle_trace_rays(self.handle, _ptr(origins), _ptr(directions), n, _ptr(triangles), _ptr(tuv), _ptr(front))
         return triangles, tuv, front
 
-    def shading_data(self, constants, triangles, barys, front, out_dirs, emission_material_index=None):
+    def shading_data(self, constants, triangles, barys, front, out_dirs, emission_material_index=None, footprints=None):
         triangles = np.ascontiguousarray(triangles, np.int32).reshape(-1)
         barys = np.ascontiguousarray(barys, np.float32).reshape(-1, 2)
         front = np.ascontiguousarray(front, np.uint8).reshape(-1)
@@ -150,13 +158,15 @@ class OracleScene:
         if emission_material_index is None:
             emission_material_index = self.scene.emission_material_index
         out = np.zeros((len(triangles), 20), np.float32)
-        lib().oracle_shading_data(self.handle, C.byref(constants), emission_material_index, _ptr(triangles), _ptr(barys), _ptr(front), _ptr(out_dirs), len(triangles), _ptr(out))
+        lib().oracle_shading_data(self.handle, C.byref(constants), emission_material_index, _ptr(triangles), _ptr(barys), _ptr(front), _ptr(out_dirs),
+                                  None if footprints is None else _ptr(np.ascontiguousarray(footprints, np.float32).reshape(-1)), len(triangles), _ptr(out))
         return out
 
-    def sample_texture(self, texture_index, uvs):
+    def sample_texture(self, texture_index, uvs, lods=None):
         uvs = np.ascontiguousarray(uvs, np.float32).reshape(-1, 2)
         out = np.zeros((len(uvs), 3), np.float32)
-        lib().oracle_sample_texture(self.handle, texture_index, _ptr(uvs), len(uvs), _ptr(out))
+        lods = None if lods is None else np.ascontiguousarray(lods, np.float32).reshape(-1)
+        lib().oracle_sample_texture(self.handle, texture_index, _ptr(uvs), None if lods is None else _ptr(lods), len(uvs), _ptr(out))
         return out
 
 

@@ -459,10 +459,13 @@ static inline vec3 dequantize_normal(float ox, float oy) {
 
 
 /* ---- texture sampling: texture() at shading_data.glsl:74-76 with the sampler
-   of src/main.c:864-873 (linear min/mag, REPEAT). Filtering is done by the
-   Vulkan driver in the reference (parity unpinned). Defined here as bilinear
-   filtering of mip level 0 with float weights; BC1/BC5 blocks are decoded
-   with 8-bit integer palettes. ---- */
+   of src/main.c:864-873 (linear min/mag/mip filters, REPEAT, all mip levels,
+   anisotropy 16). Filtering and the choice of the level of detail are done by
+   the Vulkan driver in the reference, from derivatives across a 2x2 pixel
+   quad that are undefined once neighbouring paths diverge (parity unpinned).
+   Defined here as trilinear filtering with float weights of hand-decoded
+   blocks (8-bit integer palettes), at a level of detail that follows from the
+   footprint of the path at the hit (a ray cone, see texture_lod_base()). ---- */
 
 static inline void decode_bc1_texel(const uint8_t* block, uint32_t px, uint32_t py, uint8_t rgb[3]) {
 	uint32_t c0 = block[0] | (block[1] << 8), c1 = block[2] | (block[3] << 8);
@@ -520,17 +523,83 @@ static vec3 fetch_texel(const oracle_scene_t* s, const oracle_texture_t* t, uint
 	return v3((float) rgb[0] / 255.0f, (float) rgb[1] / 255.0f, (float) rgb[2] / 255.0f);
 }
 
-static vec3 sample_texture(const oracle_scene_t* s, uint32_t texture_index, vec2 uv) {
-	const oracle_texture_t* t = &s->textures[texture_index];
-	float x = uv.x * (float) t->width - 0.5f, y = uv.y * (float) t->height - 0.5f;
+static vec3 sample_texture_level(const oracle_scene_t* s, const oracle_texture_t* t, uint32_t mip, vec2 uv) {
+	float x = uv.x * (float) (t->width >> mip) - 0.5f, y = uv.y * (float) (t->height >> mip) - 0.5f;
 	float fx0 = floorf(x), fy0 = floorf(y);
 	float wx = x - fx0, wy = y - fy0;
 	int32_t x0 = (int32_t) fx0, y0 = (int32_t) fy0;
-	vec3 t00 = fetch_texel(s, t, 0, x0, y0), t10 = fetch_texel(s, t, 0, x0 + 1, y0);
-	vec3 t01 = fetch_texel(s, t, 0, x0, y0 + 1), t11 = fetch_texel(s, t, 0, x0 + 1, y0 + 1);
+	vec3 t00 = fetch_texel(s, t, mip, x0, y0), t10 = fetch_texel(s, t, mip, x0 + 1, y0);
+	vec3 t01 = fetch_texel(s, t, mip, x0, y0 + 1), t11 = fetch_texel(s, t, mip, x0 + 1, y0 + 1);
 	vec3 top = add3(scale3(t00, 1.0f - wx), scale3(t10, wx));
 	vec3 bottom = add3(scale3(t01, 1.0f - wx), scale3(t11, wx));
 	return add3(scale3(top, 1.0f - wy), scale3(bottom, wy));
+}
+
+/* Trilinear lookup at level of detail lod (already including the size of the
+   texture), clamped to the levels that the file holds */
+static vec3 sample_texture_lod(const oracle_scene_t* s, uint32_t texture_index, vec2 uv, float lod) {
+	const oracle_texture_t* t = &s->textures[texture_index];
+	lod = fminf(fmaxf(lod, 0.0f), (float) (t->mip_count - 1));
+	float lower = floorf(lod);
+	uint32_t mip = (uint32_t) lower;
+	float blend = lod - lower;
+	vec3 fine = sample_texture_level(s, t, mip, uv);
+	if (!(blend > 0.0f))
+		return fine;
+	vec3 coarse = sample_texture_level(s, t, mip + 1, uv);
+	return add3(scale3(fine, 1.0f - blend), scale3(coarse, blend));
+}
+
+static uint32_t integer_log2(uint32_t v) {
+	uint32_t l = 0;
+	while ((1u << l) < v) ++l;
+	return l;
+}
+
+/* The level of detail rule, defined by this build (the reference leaves it to
+   the driver). A path has a footprint of some diameter where it hits a
+   triangle. The triangle maps a doubled world area world_area_2 to a doubled
+   area uv_area_2 of texture coordinates, so the footprint covers about
+   uv_area_2 / world_area_2 * footprint^2 of the unit square, times width *
+   height texels. The level at which that is one texel is
+     0.5 * (log2(uv_area_2 / world_area_2 * footprint^2) + log2(width) + log2(height)).
+   The footprint is measured across the ray (what an anisotropic filter uses
+   as its level); only beyond the sampler's anisotropy of 16, i.e. where the
+   cosine between normal and ray is below 1/16, it is stretched by
+   1 / (16 cosine). This returns the part that does not depend on the
+   texture size; very small or undefined coverage means level 0. */
+static float texture_lod_base(float uv_area_2, float world_area_2, float footprint, float cosine) {
+	float stretch = fmaxf(1.0f, 0.0625f / cosine);
+	float diameter = footprint * stretch;
+	float coverage = (uv_area_2 / world_area_2) * (diameter * diameter);
+	if (!(coverage > 1.0e-30f))
+		return -1.0e9f;
+	return 0.5f * (o_log(fminf(coverage, 1.0e30f)) * 1.44269504088896341f);
+}
+
+static vec3 sample_texture(const oracle_scene_t* s, uint32_t texture_index, vec2 uv, float lod_base) {
+	const oracle_texture_t* t = &s->textures[texture_index];
+	float size_term = 0.5f * (float) (integer_log2(t->width) + integer_log2(t->height));
+	return sample_texture_lod(s, texture_index, uv, lod_base + size_term);
+}
+
+/* Ray cones (defined by this build, see texture_lod_base()): a ray carries
+   the diameter of the path's footprint at its origin and the angle by which
+   it widens per unit distance, both cut to the upper 16 bits of their floats. */
+typedef struct { float width, spread; } cone_t;
+
+static float cut_to_upper_half(float v) { return bits_to_float(float_to_bits(v) & 0xffff0000u); }
+
+static cone_t make_cone(float width, float spread) {
+	cone_t c = { cut_to_upper_half(width), cut_to_upper_half(spread) };
+	return c;
+}
+
+/* After a bounce the cone widens by 1 / sqrt(pi * density of the sampled
+   direction), at most by 2, to at most 4 in total */
+static cone_t cone_after_bounce(float footprint, float spread, float density) {
+	float widening = fminf(2.0f, 1.0f / sqrtf(M_PI_F * density));
+	return make_cone(footprint, fminf(4.0f, spread + widening));
 }
 
 
@@ -559,8 +628,9 @@ typedef struct {
 	uint64_t ray_count;
 } context_t;
 
-/* shading_data.glsl:51-103 */
-static shading_data_t get_shading_data(const context_t* ctx, int32_t triangle_index, vec2 barycentrics, int front, vec3 out_dir) {
+/* shading_data.glsl:51-103; cone_origin and cone describe the ray that led
+   here and out_footprint receives the footprint of the path at the hit */
+static shading_data_t get_shading_data(const context_t* ctx, int32_t triangle_index, vec2 barycentrics, int front, vec3 out_dir, vec3 cone_origin, cone_t cone, float* out_footprint) {
 	const oracle_scene_t* scene = ctx->scene;
 	shading_data_t s;
 	float barys[3] = { (1.0f - barycentrics.x) - barycentrics.y, barycentrics.x, barycentrics.y };
@@ -584,9 +654,17 @@ static shading_data_t get_shading_data(const context_t* ctx, int32_t triangle_in
 	}
 	normal_geo = normalize3(normal_geo);
 	uint32_t material_index = scene->materials[triangle_index];
-	vec3 base_color_tex = sample_texture(scene, 3 * material_index + 0, tex_coord);
-	vec3 specular_tex = sample_texture(scene, 3 * material_index + 1, tex_coord);
-	vec3 normal_tex = sample_texture(scene, 3 * material_index + 2, tex_coord);
+	/* Level of detail of the three lookups */
+	vec3 travelled = sub3(s.pos, cone_origin);
+	float footprint = fmaf(cone.spread, sqrtf(dot3(travelled, travelled)), cone.width);
+	if (out_footprint)
+		*out_footprint = footprint;
+	vec3 face_normal = cross3(sub3(poss[1], poss[0]), sub3(poss[2], poss[0]));
+	float uv_area_2 = fabsf((tex_coords[1].x - tex_coords[0].x) * (tex_coords[2].y - tex_coords[0].y) - (tex_coords[2].x - tex_coords[0].x) * (tex_coords[1].y - tex_coords[0].y));
+	float lod_base = texture_lod_base(uv_area_2, sqrtf(dot3(face_normal, face_normal)), footprint, fabsf(dot3(normal_geo, out_dir)));
+	vec3 base_color_tex = sample_texture(scene, 3 * material_index + 0, tex_coord, lod_base);
+	vec3 specular_tex = sample_texture(scene, 3 * material_index + 1, tex_coord, lod_base);
+	vec3 normal_tex = sample_texture(scene, 3 * material_index + 2, tex_coord, lod_base);
 	vec3 normal_local;
 	normal_local.x = normal_tex.x * 2.0f - 1.0f;
 	normal_local.y = normal_tex.y * 2.0f - 1.0f;
@@ -1078,7 +1156,7 @@ static float get_lights_density_tree(const context_t* ctx, vec3 shading_pos, vec
 }
 
 /* :181-199 */
-static int trace_ray(context_t* ctx, shading_data_t* out, vec3 ray_origin, vec3 ray_dir) {
+static int trace_ray(context_t* ctx, shading_data_t* out, vec3 ray_origin, vec3 ray_dir, cone_t cone, float* out_footprint) {
 	++ctx->ray_count;
 	hit_t hit = trace_closest(ctx->scene, ray_origin, ray_dir, 1.0e-3f, 1e38f);
 	if (hit.triangle < 0) {
@@ -1087,7 +1165,7 @@ static int trace_ray(context_t* ctx, shading_data_t* out, vec3 ray_origin, vec3 
 		return 0;
 	}
 	vec2 barys = { hit.u, hit.v };
-	*out = get_shading_data(ctx, hit.triangle, barys, hit.front, neg3(ray_dir));
+	*out = get_shading_data(ctx, hit.triangle, barys, hit.front, neg3(ray_dir), ray_origin, cone, out_footprint);
 	return 1;
 }
 
@@ -1103,12 +1181,13 @@ static vec3 trace_ray_emission(context_t* ctx, vec3 ray_origin, vec3 ray_dir) {
 }
 
 /* :224-247 and :258-281; spherical != 0 selects path_trace_spherical */
-static vec3 path_trace_uniform(context_t* ctx, vec3 ray_origin, vec3 ray_dir, uint32_t seed[2], int spherical) {
+static vec3 path_trace_uniform(context_t* ctx, vec3 ray_origin, vec3 ray_dir, cone_t cone, uint32_t seed[2], int spherical) {
 	vec3 throughput_weight = v3(1.0f, 1.0f, 1.0f);
 	vec3 radiance = v3(0.0f, 0.0f, 0.0f);
 	for (uint32_t k = 1; k != ctx->path_length + 1; ++k) {
 		shading_data_t s;
-		int hit = trace_ray(ctx, &s, ray_origin, ray_dir);
+		float footprint = 0.0f;
+		int hit = trace_ray(ctx, &s, ray_origin, ray_dir, cone, &footprint);
 		radiance = add3(radiance, mul3(throughput_weight, s.emission));
 		if (hit && k < ctx->path_length) {
 			mat3_t shading_to_world_space = get_shading_space(s.normal);
@@ -1119,6 +1198,7 @@ static vec3 path_trace_uniform(context_t* ctx, vec3 ray_origin, vec3 ray_dir, ui
 			float lambert_in = sampled_dir.z;
 			float density = spherical ? get_hemisphere_spherical_density(sampled_dir.z) : get_hemisphere_psa_density(sampled_dir.z);
 			throughput_weight = mul3(throughput_weight, div3(scale3(frostbite_brdf(&s, ray_dir), lambert_in), density));
+			cone = cone_after_bounce(footprint, cone.spread, density);
 		}
 		else
 			break;
@@ -1127,12 +1207,13 @@ static vec3 path_trace_uniform(context_t* ctx, vec3 ray_origin, vec3 ray_dir, ui
 }
 
 /* :286-311 */
-static vec3 path_trace_brdf(context_t* ctx, vec3 ray_origin, vec3 ray_dir, uint32_t seed[2]) {
+static vec3 path_trace_brdf(context_t* ctx, vec3 ray_origin, vec3 ray_dir, cone_t cone, uint32_t seed[2]) {
 	vec3 throughput_weight = v3(1.0f, 1.0f, 1.0f);
 	vec3 radiance = v3(0.0f, 0.0f, 0.0f);
 	for (uint32_t k = 1; k != ctx->path_length + 1; ++k) {
 		shading_data_t s;
-		int hit = trace_ray(ctx, &s, ray_origin, ray_dir);
+		float footprint = 0.0f;
+		int hit = trace_ray(ctx, &s, ray_origin, ray_dir, cone, &footprint);
 		radiance = add3(radiance, mul3(throughput_weight, s.emission));
 		if (hit && k < ctx->path_length) {
 			ray_origin = s.pos;
@@ -1142,6 +1223,7 @@ static vec3 path_trace_brdf(context_t* ctx, vec3 ray_origin, vec3 ray_dir, uint3
 			if (lambert_in <= 0.0f)
 				break;
 			throughput_weight = mul3(throughput_weight, div3(scale3(frostbite_brdf(&s, ray_dir), lambert_in), density));
+			cone = cone_after_bounce(footprint, cone.spread, density);
 		}
 		else
 			break;
@@ -1150,13 +1232,14 @@ static vec3 path_trace_brdf(context_t* ctx, vec3 ray_origin, vec3 ray_dir, uint3
 }
 
 /* :315-362 */
-static vec3 path_trace_nee(context_t* ctx, vec3 ray_origin, vec3 ray_dir, uint32_t seed[2]) {
+static vec3 path_trace_nee(context_t* ctx, vec3 ray_origin, vec3 ray_dir, cone_t cone, uint32_t seed[2]) {
 	vec3 throughput_weight = v3(1.0f, 1.0f, 1.0f);
 	vec3 nee_throughput_weight = throughput_weight;
 	vec3 radiance = v3(0.0f, 0.0f, 0.0f);
 	for (uint32_t k = 1; k != ctx->path_length + 1; ++k) {
 		shading_data_t s;
-		int hit = trace_ray(ctx, &s, ray_origin, ray_dir);
+		float footprint = 0.0f;
+		int hit = trace_ray(ctx, &s, ray_origin, ray_dir, cone, &footprint);
 		radiance = add3(radiance, mul3(nee_throughput_weight, s.emission));
 		if (hit && k < ctx->path_length) {
 			float total_light_importance = 0.0f, sampled_light_density = 0.0f;
@@ -1187,6 +1270,7 @@ static vec3 path_trace_nee(context_t* ctx, vec3 ray_origin, vec3 ray_dir, uint32
 			vec3 brdf_lambert_1 = scale3(frostbite_brdf(&s, ray_dir), lambert_in_1);
 			nee_throughput_weight = mul3(throughput_weight, div3(brdf_lambert_1, light_density_1 + brdf_density_1));
 			throughput_weight = mul3(throughput_weight, scale3(brdf_lambert_1, 1.0f / brdf_density_1));
+			cone = cone_after_bounce(footprint, cone.spread, brdf_density_1);
 		}
 		else
 			break;
@@ -1222,16 +1306,8 @@ static vec3 get_camera_ray_direction(vec2 ray_tex_coord, const float m[16]) {
 	return normalize3(d);
 }
 
-/* pathtrace.frag.glsl:365-386: seed, jitter and primary ray of one pixel */
-static void get_primary_ray(const oracle_constants_t* c, uint32_t x, uint32_t y, uint32_t frame_index, uint32_t seed[2], vec3* ray_origin, vec3* ray_dir) {
-	seed[0] = x ^ (frame_index << 16);
-	seed[1] = y ^ ((frame_index + 237u) << 16);
-	const float std = 0.9f;
-	vec2 randoms = get_random_numbers(seed);
-	randoms.x = 2.0f * randoms.x - 1.0f;
-	randoms.y = 2.0f * randoms.y - 1.0f;
-	float scale = std * sqrtf(2.0f);
-	vec2 jittered = { ((float) x + 0.5f) + scale * oracle_erfinv(randoms.x), ((float) y + 0.5f) + scale * oracle_erfinv(randoms.y) };
+/* The camera ray through a point of the image plane given in pixels, pathtrace.frag.glsl:374-386 */
+static void get_camera_ray(const oracle_constants_t* c, vec2 jittered, vec3* ray_origin, vec3* ray_dir) {
 	if (c->camera_type <= 1) {
 		vec2 ray_tex_coord = { jittered.x * c->inv_viewport_size[0], jittered.y * c->inv_viewport_size[1] };
 		*ray_origin = get_camera_ray_origin(ray_tex_coord, c->projection_to_world_space);
@@ -1246,16 +1322,44 @@ static void get_primary_ray(const oracle_constants_t* c, uint32_t x, uint32_t y,
 	}
 }
 
+static float length3(vec3 v) { return sqrtf(dot3(v, v)); }
+
+/* pathtrace.frag.glsl:365-386: seed, jitter and primary ray of one pixel.
+   out_cone (may be NULL) receives the ray's cone: how far apart the rays one
+   pixel to the right and one pixel down start, and how far their directions
+   are from this one's, the smaller of the two each. */
+static void get_primary_ray(const oracle_constants_t* c, uint32_t x, uint32_t y, uint32_t frame_index, uint32_t seed[2], vec3* ray_origin, vec3* ray_dir, cone_t* out_cone) {
+	seed[0] = x ^ (frame_index << 16);
+	seed[1] = y ^ ((frame_index + 237u) << 16);
+	const float std = 0.9f;
+	vec2 randoms = get_random_numbers(seed);
+	randoms.x = 2.0f * randoms.x - 1.0f;
+	randoms.y = 2.0f * randoms.y - 1.0f;
+	float scale = std * sqrtf(2.0f);
+	vec2 jittered = { ((float) x + 0.5f) + scale * oracle_erfinv(randoms.x), ((float) y + 0.5f) + scale * oracle_erfinv(randoms.y) };
+	get_camera_ray(c, jittered, ray_origin, ray_dir);
+	if (out_cone) {
+		vec2 right = { jittered.x + 1.0f, jittered.y }, down = { jittered.x, jittered.y + 1.0f };
+		vec3 o_right, d_right, o_down, d_down;
+		get_camera_ray(c, right, &o_right, &d_right);
+		get_camera_ray(c, down, &o_down, &d_down);
+		float width = fminf(length3(sub3(o_right, *ray_origin)), length3(sub3(o_down, *ray_origin)));
+		float spread = fminf(length3(sub3(d_right, *ray_dir)), length3(sub3(d_down, *ray_dir)));
+		*out_cone = make_cone(width, spread);
+	}
+}
+
 /* pathtrace.frag.glsl:365-398 */
 static vec3 render_pixel(context_t* ctx, uint32_t x, uint32_t y, uint32_t frame_index) {
 	uint32_t seed[2];
 	vec3 ray_origin, ray_dir;
-	get_primary_ray(ctx->c, x, y, frame_index, seed, &ray_origin, &ray_dir);
+	cone_t cone;
+	get_primary_ray(ctx->c, x, y, frame_index, seed, &ray_origin, &ray_dir, &cone);
 	switch (ctx->strategy) {
-		case ORACLE_STRATEGY_SPHERICAL: return path_trace_uniform(ctx, ray_origin, ray_dir, seed, 1);
-		case ORACLE_STRATEGY_PSA: return path_trace_uniform(ctx, ray_origin, ray_dir, seed, 0);
-		case ORACLE_STRATEGY_BRDF: return path_trace_brdf(ctx, ray_origin, ray_dir, seed);
-		default: return path_trace_nee(ctx, ray_origin, ray_dir, seed);
+		case ORACLE_STRATEGY_SPHERICAL: return path_trace_uniform(ctx, ray_origin, ray_dir, cone, seed, 1);
+		case ORACLE_STRATEGY_PSA: return path_trace_uniform(ctx, ray_origin, ray_dir, cone, seed, 0);
+		case ORACLE_STRATEGY_BRDF: return path_trace_brdf(ctx, ray_origin, ray_dir, cone, seed);
+		default: return path_trace_nee(ctx, ray_origin, ray_dir, cone, seed);
 	}
 }
 
@@ -1365,12 +1469,26 @@ void oracle_primary_hits(const oracle_scene_t* scene, const oracle_constants_t* 
 		for (uint32_t x = 0; x != width; ++x) {
 			uint32_t seed[2];
 			vec3 o, d;
-			get_primary_ray(constants, x, y, frame_index, seed, &o, &d);
+			get_primary_ray(constants, x, y, frame_index, seed, &o, &d, NULL);
 			hit_t hit = trace_closest(scene, o, d, 1.0e-3f, 1e38f);
 			uint64_t i = (uint64_t) y * width + x;
 			triangle_indices[i] = hit.triangle;
 			if (barycentrics) { barycentrics[2 * i] = hit.u; barycentrics[2 * i + 1] = hit.v; }
 			if (front) front[i] = (uint8_t) hit.front;
+		}
+	}
+}
+
+void oracle_primary_cones(const oracle_constants_t* constants, uint32_t frame_index, float* widths, float* spreads) {
+	uint32_t width = (uint32_t) constants->viewport_size[0], height = (uint32_t) constants->viewport_size[1];
+	for (uint32_t y = 0; y != height; ++y) {
+		for (uint32_t x = 0; x != width; ++x) {
+			uint32_t seed[2];
+			vec3 o, d;
+			cone_t cone;
+			get_primary_ray(constants, x, y, frame_index, seed, &o, &d, &cone);
+			widths[(uint64_t) y * width + x] = cone.width;
+			spreads[(uint64_t) y * width + x] = cone.spread;
 		}
 	}
 }
@@ -1397,7 +1515,7 @@ void oracle_trace_rays(const oracle_scene_t* scene, const float* origins, const 
 }
 
 void oracle_shading_data(const oracle_scene_t* scene, const oracle_constants_t* constants, uint32_t emission_material_index,
-	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out)
+	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, const float* footprints, uint32_t count, float* out)
 {
 	context_t ctx;
 	memset(&ctx, 0, sizeof(ctx));
@@ -1406,7 +1524,9 @@ void oracle_shading_data(const oracle_scene_t* scene, const oracle_constants_t* 
 	ctx.emission_material_index = emission_material_index;
 	for (uint32_t i = 0; i != count; ++i) {
 		vec2 barys = { barycentrics[2 * i], barycentrics[2 * i + 1] };
-		shading_data_t s = get_shading_data(&ctx, triangle_indices[i], barys, front[i], v3(out_dirs[3 * i], out_dirs[3 * i + 1], out_dirs[3 * i + 2]));
+		/* A cone that does not widen: the footprint is the given one wherever the hit lies */
+		cone_t cone = { footprints ? footprints[i] : 0.0f, 0.0f };
+		shading_data_t s = get_shading_data(&ctx, triangle_indices[i], barys, front[i], v3(out_dirs[3 * i], out_dirs[3 * i + 1], out_dirs[3 * i + 2]), v3(0.0f, 0.0f, 0.0f), cone, NULL);
 		float* o = &out[20 * i];
 		o[0] = s.pos.x; o[1] = s.pos.y; o[2] = s.pos.z;
 		o[3] = s.normal.x; o[4] = s.normal.y; o[5] = s.normal.z;
@@ -1419,10 +1539,10 @@ void oracle_shading_data(const oracle_scene_t* scene, const oracle_constants_t* 
 	}
 }
 
-void oracle_sample_texture(const oracle_scene_t* scene, uint32_t texture_index, const float* uvs, uint32_t count, float* out) {
+void oracle_sample_texture(const oracle_scene_t* scene, uint32_t texture_index, const float* uvs, const float* lods, uint32_t count, float* out) {
 	for (uint32_t i = 0; i != count; ++i) {
 		vec2 uv = { uvs[2 * i], uvs[2 * i + 1] };
-		vec3 r = sample_texture(scene, texture_index, uv);
+		vec3 r = sample_texture_lod(scene, texture_index, uv, lods ? lods[i] : 0.0f);
 		out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
 	}
 }

@@ -14,7 +14,8 @@
  * consistency of its four unbiased estimators. Ray/triangle intersection and
  * texture filtering happen inside the Vulkan driver in the reference and are
  * "parity unpinned": the oracle defines them (watertight ray/triangle test,
- * float bilinear filtering of hand-decoded BC1/BC5 blocks).
+ * float trilinear filtering of hand-decoded BC1/BC5 blocks at a level of
+ * detail taken from the footprint of the path, a ray cone).
  */
 #ifndef PT_ORACLE_H
 #define PT_ORACLE_H
@@ -96,6 +97,11 @@ uint64_t oracle_render_light_sampling(const oracle_scene_t* scene, const oracle_
 void oracle_primary_hits(const oracle_scene_t* scene, const oracle_constants_t* constants,
 	uint32_t frame_index, int32_t* triangle_indices, float* barycentrics, uint8_t* front);
 
+/* The cone of every primary ray of one frame (width * height floats each):
+ * the diameter of the footprint at the ray's origin and its growth per unit
+ * distance, as the level-of-detail rule of this build defines them. */
+void oracle_primary_cones(const oracle_constants_t* constants, uint32_t frame_index, float* widths, float* spreads);
+
 /* The first draw_count outputs (2 floats each) of get_random_numbers() for
  * pixel (x, y) in frame frame_index, and the seed after each draw. */
 void oracle_rng_stream(uint32_t x, uint32_t y, uint32_t frame_index, uint32_t draw_count, float* out_randoms, uint32_t* out_seeds);
@@ -106,13 +112,16 @@ void oracle_trace_rays(const oracle_scene_t* scene, const float* origins, const 
 	int32_t* triangle_indices, float* t_u_v, uint8_t* front);
 
 /* Evaluates get_shading_data() for given hits; out has 20 floats per hit in
- * the member order of shading_data_t (shading_data.glsl:19-39). */
+ * the member order of shading_data_t (shading_data.glsl:19-39). footprints
+ * (may be NULL = zeros) holds the diameter of the path's footprint at each
+ * hit, which sets the level of detail of the texture lookups. */
 void oracle_shading_data(const oracle_scene_t* scene, const oracle_constants_t* constants, uint32_t emission_material_index,
-	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out);
+	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, const float* footprints, uint32_t count, float* out);
 
 /* Samples texture texture_index at the given uv coordinates (2 floats
- * each); writes 3 floats per sample (BC5: r, g, 0). */
-void oracle_sample_texture(const oracle_scene_t* scene, uint32_t texture_index, const float* uvs, uint32_t count, float* out);
+ * each) and levels of detail (NULL = level 0), trilinearly; writes 3 floats
+ * per sample (BC5: r, g, 0). */
+void oracle_sample_texture(const oracle_scene_t* scene, uint32_t texture_index, const float* uvs, const float* lods, uint32_t count, float* out);
 
 /* Elementary functions shared by definition with the HIP kernels. */
 void oracle_sincos(float x, float* out_sin, float* out_cos);

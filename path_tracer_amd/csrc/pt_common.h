@@ -184,15 +184,24 @@ struct PtTexture {
 // What the shading kernels read per texture, small enough that the table of a
 // whole scene (at most 768 textures) stays in the vector L1: the offset of
 // the texture's texels in the blob in units of 16 bytes (PtTexture.mip_offsets[0]
-// holds it), and log2 width | log2 height << 8 | VkFormat << 16
+// holds it; the other levels follow level 0 without gaps), and
+// log2 width | log2 height << 8 | VkFormat << 16 | mip levels << 24
 PT_FN u32x2 pt_pack_texture(const PtTexture& t) {
 	uint32_t log_w = 0, log_h = 0;
 	while ((1u << log_w) < t.width) ++log_w;
 	while ((1u << log_h) < t.height) ++log_h;
 	u32x2 e;
 	e.x = (uint32_t) (t.mip_offsets[0] >> 4);
-	e.y = log_w | (log_h << 8) | (t.format << 16);
+	e.y = log_w | (log_h << 8) | (t.format << 16) | (t.mip_count << 24);
 	return e;
+}
+
+// Texels of a 2^log_w x 2^log_h texture that precede mip level `level` when
+// the levels are stored back to back: the sum of 2^(log_w + log_h - 2 i) over
+// i < level, which is (4^level - 1) / 3 * 2^(log_w + log_h + 2 - 2 level)
+PT_FN uint64_t pt_mip_texel_offset(uint32_t log_w, uint32_t log_h, uint32_t level) {
+	uint64_t thirds = 0x5555555555555555ull & ((1ull << (2 * level)) - 1ull);
+	return thirds << (log_w + log_h + 2 - 2 * level);
 }
 
 // Everything that shading reads of a triangle, in one 64-byte line: the

@@ -286,10 +286,11 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtCons
 	bool inside = pt_path_to_pixel(batch, p, &x, &y, &frame_slot);
 	uint32_t sx = 0, sy = 0;
 	v3 origin = mk3(0.0f, 0.0f, 0.0f), dir = mk3(0.0f, 0.0f, 1.0f);
+	float cone_width = 0.0f, cone_spread = 0.0f;
 	if (inside)
-		pt_primary_ray(*constants, x, y, batch.first_frame_index + frame_slot * batch.frame_stride, sx, sy, &origin, &dir);
+		pt_primary_ray(*constants, x, y, batch.first_frame_index + frame_slot * batch.frame_stride, sx, sy, &origin, &dir, &cone_width, &cone_spread);
 	wf.ray_o[0][p] = mk4(origin.x, origin.y, origin.z, pt_as_float(inside ? p : PT_INVALID));
-	wf.ray_d[0][p] = mk4(dir.x, dir.y, dir.z, 0.0f);
+	wf.ray_d[0][p] = mk4(dir.x, dir.y, dir.z, pt_pack_cone(cone_width, cone_spread));
 	// The path state (throughput weights of one, the seed) is not written here:
 	// shading the first vertex derives it from the path index again, which is
 	// cheaper than 32 bytes written and 32 read per path
@@ -361,14 +362,13 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_shadow(PtTraceArgs a) 
 		});
 }
 
-// Decodes mip 0 of one BC1 / BC5 texture into tiled 8-bit texels (pt_fetch_texel() reads them)
-__global__ void __launch_bounds__(PT_BLOCK) k_decode_texture(const uint8_t* bc_mip_0, uint32_t* texels, uint32_t packed_info, uint32_t texel_count) {
+// Decodes one mip level (2^log_w texels wide) of a BC1 / BC5 texture into tiled 8-bit texels (pt_fetch_texel() reads them)
+__global__ void __launch_bounds__(PT_BLOCK) k_decode_texture(const uint8_t* bc_mip, uint32_t* texels, uint32_t log_w, uint32_t format, uint32_t texel_count) {
 	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
 	if (i >= texel_count)
 		return;
-	uint32_t log_w = packed_info & 0xffu, format = packed_info >> 16;
 	uint32_t x = i & ((1u << log_w) - 1u), y = i >> log_w;
-	texels[pt_texel_index(log_w, x, y)] = pt_decode_texel(bc_mip_0, log_w, format, x, y);
+	texels[pt_texel_index(log_w, x, y)] = pt_decode_texel(bc_mip, log_w, format, x, y);
 }
 
 // The three .vks arrays of a triangle side by side in one 64-byte record
@@ -437,7 +437,9 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, 5) k_shade(PtShadeArgs a) {
 		active = path != PT_INVALID;
 	}
 	if (active) {
-		f32x4 d = a.wf.ray_d[a.parity][slot];
+		// The direction carries the ray's cone in its fourth word; the origin is
+		// needed for the distance that the cone has travelled
+		f32x4 d = a.wf.ray_d[a.parity][slot], o = a.wf.ray_o[a.parity][slot];
 		v3 throughput = mk3(1.0f, 1.0f, 1.0f), nee_throughput = mk3(1.0f, 1.0f, 1.0f), emitted = mk3(0.0f, 0.0f, 0.0f);
 		uint32_t sx, sy;
 		if (a.k == 1) {
@@ -457,7 +459,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, 5) k_shade(PtShadeArgs a) {
 		if (a.visit_counters && !missed)
 			atomicAdd(&a.visit_counters[4], 1ull);
 		r = pt_shade_vertex(a.scene, *a.constants, light_cache, STRATEGY, a.path_length, a.k,
-			missed ? PT_INVALID : (hit.x & 0x7fffffffu), pt_as_float(hit.y), pt_as_float(hit.z), (hit.x >> 31) != 0, mk3(d.x, d.y, d.z),
+			missed ? PT_INVALID : (hit.x & 0x7fffffffu), pt_as_float(hit.y), pt_as_float(hit.z), (hit.x >> 31) != 0, mk3(o.x, o.y, o.z), mk3(d.x, d.y, d.z), d.w,
 			emitted, throughput, nee_throughput, sx, sy);
 		// Emission is zero at most vertices; radiance + 0 is the radiance (it is
 		// never -0), so only other terms, NaN included, touch the path's radiance
@@ -475,7 +477,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, 5) k_shade(PtShadeArgs a) {
 	pt_block_push_2<PT_SHADE_BLOCK>(&a.wf.ext_count[a.k], r.continues, &a.wf.shadow_count[a.k], r.shadow, &next_slot, &shadow_slot);
 	if (r.continues) {
 		a.wf.ray_o[a.parity ^ 1][next_slot] = mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path));
-		a.wf.ray_d[a.parity ^ 1][next_slot] = mk4(r.next_dir.x, r.next_dir.y, r.next_dir.z, 0.0f);
+		a.wf.ray_d[a.parity ^ 1][next_slot] = mk4(r.next_dir.x, r.next_dir.y, r.next_dir.z, r.next_cone);
 	}
 	if (r.shadow) {
 		a.wf.sh_o[shadow_slot] = mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path));
@@ -583,12 +585,13 @@ __global__ void __launch_bounds__(PT_BLOCK) k_stage_user_rays(const float* origi
 	staged_directions[i] = mk4(directions[3 * (uint64_t) i], directions[3 * (uint64_t) i + 1], directions[3 * (uint64_t) i + 2], 0.0f);
 }
 
-__global__ void __launch_bounds__(PT_BLOCK) k_shading_data(PtSceneView scene, const PtConstants* constants, const int32_t* triangles, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out) {
+__global__ void __launch_bounds__(PT_BLOCK) k_shading_data(PtSceneView scene, const PtConstants* constants, const int32_t* triangles, const float* barycentrics, const uint8_t* front, const float* out_dirs, const float* footprints, uint32_t count, float* out) {
 	pt_stage_srgb_table(scene.srgb_to_linear);
 	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
 	if (i >= count)
 		return;
-	PtShadingData s = pt_shading_data(scene, *constants, (uint32_t) triangles[i], barycentrics[2 * i], barycentrics[2 * i + 1], front[i] != 0, mk3(out_dirs[3 * i], out_dirs[3 * i + 1], out_dirs[3 * i + 2]));
+	PtShadingData s = pt_shading_data(scene, *constants, (uint32_t) triangles[i], barycentrics[2 * i], barycentrics[2 * i + 1], front[i] != 0, mk3(out_dirs[3 * i], out_dirs[3 * i + 1], out_dirs[3 * i + 2]),
+		mk3(0.0f, 0.0f, 0.0f), footprints ? footprints[i] : 0.0f, 0.0f);
 	float* o = &out[20 * (uint64_t) i];
 	o[0] = s.pos.x; o[1] = s.pos.y; o[2] = s.pos.z;
 	o[3] = s.normal.x; o[4] = s.normal.y; o[5] = s.normal.z;
@@ -1030,10 +1033,19 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 			printf("Texture %u is not supported (format %u, %ux%u, %u mipmaps).\n", i, t->format, t->width, t->height, t->mip_count);
 			return 1;
 		}
-		uint64_t expected = (uint64_t) ((t->width + 3) / 4) * ((t->height + 3) / 4) * ((t->format == 141) ? 16 : 8);
-		if (t->mip_sizes[0] != expected || !t->mip_data[0]) {
-			printf("The data block for mipmap 0 of texture %u was supposed to have %llu bytes but had %llu bytes.\n", i, (unsigned long long) expected, (unsigned long long) t->mip_sizes[0]);
-			return 1;
+		// Block compression goes down to 4x4 texels (tools/texture_conversion/main.c:291-293),
+		// so the smaller extent allows log2(extent) - 1 levels; level m has the extent >> m
+		for (uint32_t m = 0; m != t->mip_count; ++m) {
+			uint32_t mip_w = t->width >> m, mip_h = t->height >> m;
+			if (mip_w < 4 || mip_h < 4) {
+				printf("Texture %u (%ux%u) has %u mipmaps, but block-compressed mipmaps end at an extent of 4.\n", i, t->width, t->height, t->mip_count);
+				return 1;
+			}
+			uint64_t expected = (uint64_t) (mip_w / 4) * (mip_h / 4) * ((t->format == 141) ? 16 : 8);
+			if (t->mip_sizes[m] != expected || !t->mip_data[m]) {
+				printf("The data block for mipmap %u of texture %u was supposed to have %llu bytes but had %llu bytes.\n", m, i, (unsigned long long) expected, (unsigned long long) t->mip_sizes[m]);
+				return 1;
+			}
 		}
 	}
 	// A material index beyond the table would send the shading kernels past the
@@ -1107,24 +1119,30 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 		}
 		if (hipMemcpyAsync(s->srgb_to_linear, table, sizeof(table), hipMemcpyHostToDevice, s->stream) != hipSuccess)
 			break;
-		// The texels of all textures decoded into one blob (pt_fetch_texel()):
-		// the block-compressed mip 0 payloads go to the GPU, a kernel decodes them
+		// The texels of all mip levels of all textures decoded into one blob
+		// (pt_fetch_texel()): the block-compressed payloads go to the GPU as they
+		// are, a kernel decodes them
 		std::vector<PtTexture> descs(texture_count ? texture_count : 1);
-		std::vector<uint64_t> bc_offsets(texture_count ? texture_count : 1);
+		std::vector<uint64_t> bc_offsets;
 		uint64_t texel_bytes = 0, bc_bytes = 0;
 		for (uint32_t i = 0; i != texture_count; ++i) {
 			descs[i].width = textures[i].width;
 			descs[i].height = textures[i].height;
 			descs[i].format = textures[i].format;
-			descs[i].mip_count = 1;
-			descs[i].mip_offsets[0] = texel_bytes;
-			texel_bytes += (uint64_t) textures[i].width * textures[i].height * 4;
-			bc_offsets[i] = bc_bytes;
-			bc_bytes += (textures[i].mip_sizes[0] + 15) & ~15ull;
+			descs[i].mip_count = textures[i].mip_count;
+			for (uint32_t m = 0; m != textures[i].mip_count; ++m) {
+				descs[i].mip_offsets[m] = texel_bytes;
+				texel_bytes += (uint64_t) (textures[i].width >> m) * (textures[i].height >> m) * 4;
+				bc_offsets.push_back(bc_bytes);
+				bc_bytes += (textures[i].mip_sizes[m] + 15) & ~15ull;
+			}
+			// One 64-byte line per 4x4 tile: every texture starts on one
+			texel_bytes = (texel_bytes + 63) & ~63ull;
 		}
 		std::vector<uint8_t> bc_blob(bc_bytes ? bc_bytes : 16);
-		for (uint32_t i = 0; i != texture_count; ++i)
-			memcpy(&bc_blob[bc_offsets[i]], textures[i].mip_data[0], textures[i].mip_sizes[0]);
+		for (uint32_t i = 0, level = 0; i != texture_count; ++i)
+			for (uint32_t m = 0; m != textures[i].mip_count; ++m, ++level)
+				memcpy(&bc_blob[bc_offsets[level]], textures[i].mip_data[m], textures[i].mip_sizes[m]);
 		std::vector<u32x2> packed(descs.size());
 		for (size_t i = 0; i != descs.size(); ++i)
 			packed[i] = (i < texture_count) ? pt_pack_texture(descs[i]) : u32x2{ 0u, 0u };
@@ -1136,10 +1154,19 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 		bool textures_failed = pt_alloc(&s->texture_blob, texel_bytes ? texel_bytes : 16) || pt_alloc(&device_bc_blob, bc_blob.size()) || pt_alloc(&s->texture_table, packed.size())
 			|| hipMemcpyAsync(device_bc_blob, bc_blob.data(), bc_blob.size(), hipMemcpyHostToDevice, s->stream) != hipSuccess
 			|| hipMemcpyAsync(s->texture_table, packed.data(), packed.size() * sizeof(u32x2), hipMemcpyHostToDevice, s->stream) != hipSuccess;
-		for (uint32_t i = 0; i != texture_count && !textures_failed; ++i) {
-			uint32_t texels = textures[i].width * textures[i].height;
-			hipLaunchKernelGGL(k_decode_texture, dim3(pt_grid(texels)), dim3(PT_BLOCK), 0, s->stream,
-				device_bc_blob + bc_offsets[i], (uint32_t*) (s->texture_blob + descs[i].mip_offsets[0]), packed[i].y, texels);
+		for (uint32_t i = 0, level = 0; i != texture_count && !textures_failed; ++i) {
+			uint32_t log_w = packed[i].y & 0xffu, log_h = (packed[i].y >> 8) & 0xffu;
+			for (uint32_t m = 0; m != textures[i].mip_count; ++m, ++level) {
+				uint32_t texels = (textures[i].width >> m) * (textures[i].height >> m);
+				// The levels follow each other as pt_mip_texel_offset() says
+				if (descs[i].mip_offsets[m] != descs[i].mip_offsets[0] + 4 * pt_mip_texel_offset(log_w, log_h, m)) {
+					printf("Internal error: mip level %u of texture %u is misplaced.\n", m, i);
+					textures_failed = true;
+					break;
+				}
+				hipLaunchKernelGGL(k_decode_texture, dim3(pt_grid(texels)), dim3(PT_BLOCK), 0, s->stream,
+					device_bc_blob + bc_offsets[level], (uint32_t*) (s->texture_blob + descs[i].mip_offsets[m]), log_w - m, textures[i].format, texels);
+			}
 		}
 		textures_failed = textures_failed || hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess;
 		hipFree(device_bc_blob);
@@ -1720,7 +1747,7 @@ static int pt_trace_rays_no_alloc_impl(pt_scene_t* s, const float* device_origin
 }
 
 static int pt_evaluate_shading_data_impl(pt_scene_t* s, const pt_constants_t* constants,
-	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs,
+	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, const float* footprints,
 	uint32_t count, float* out_shading_data)
 {
 	if (!s || !constants || (count && (!triangle_indices || !barycentrics || !front || !out_dirs || !out_shading_data)))
@@ -1735,10 +1762,12 @@ static int pt_evaluate_shading_data_impl(pt_scene_t* s, const pt_constants_t* co
 	}
 	PT_CHECK(hipSetDevice(s->device));
 	PT_CHECK(hipStreamSynchronize(s->stream));
-	int32_t* d_triangles = NULL; float* d_barycentrics = NULL; uint8_t* d_front = NULL; float* d_dirs = NULL; float* d_out = NULL;
+	int32_t* d_triangles = NULL; float* d_barycentrics = NULL; uint8_t* d_front = NULL; float* d_dirs = NULL; float* d_footprints = NULL; float* d_out = NULL;
 	int result = 1;
 	do {
 		if (pt_alloc(&d_triangles, count) || pt_alloc(&d_barycentrics, 2 * (uint64_t) count) || pt_alloc(&d_front, count) || pt_alloc(&d_dirs, 3 * (uint64_t) count) || pt_alloc(&d_out, 20 * (uint64_t) count))
+			break;
+		if (footprints && (pt_alloc(&d_footprints, count) || hipMemcpyAsync(d_footprints, footprints, sizeof(float) * count, hipMemcpyHostToDevice, s->stream) != hipSuccess))
 			break;
 		if (hipMemcpyAsync(s->constants, constants, sizeof(PtConstants), hipMemcpyHostToDevice, s->stream) != hipSuccess
 			|| hipMemcpyAsync(d_triangles, triangle_indices, sizeof(int32_t) * count, hipMemcpyHostToDevice, s->stream) != hipSuccess
@@ -1746,13 +1775,13 @@ static int pt_evaluate_shading_data_impl(pt_scene_t* s, const pt_constants_t* co
 			|| hipMemcpyAsync(d_front, front, count, hipMemcpyHostToDevice, s->stream) != hipSuccess
 			|| hipMemcpyAsync(d_dirs, out_dirs, sizeof(float) * 3 * count, hipMemcpyHostToDevice, s->stream) != hipSuccess)
 			break;
-		hipLaunchKernelGGL(k_shading_data, dim3(pt_grid(count)), dim3(PT_BLOCK), 0, s->stream, pt_scene_view(s), s->constants, d_triangles, d_barycentrics, d_front, d_dirs, count, d_out);
+		hipLaunchKernelGGL(k_shading_data, dim3(pt_grid(count)), dim3(PT_BLOCK), 0, s->stream, pt_scene_view(s), s->constants, d_triangles, d_barycentrics, d_front, d_dirs, (const float*) d_footprints, count, d_out);
 		if (hipMemcpyAsync(out_shading_data, d_out, sizeof(float) * 20 * count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
 			|| hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess)
 			break;
 		result = 0;
 	} while (0);
-	hipFree(d_triangles); hipFree(d_barycentrics); hipFree(d_front); hipFree(d_dirs); hipFree(d_out);
+	hipFree(d_triangles); hipFree(d_barycentrics); hipFree(d_front); hipFree(d_dirs); hipFree(d_footprints); hipFree(d_out);
 	if (result)
 		printf("Failed to evaluate shading data on the GPU.\n");
 	return result;
@@ -1835,8 +1864,8 @@ extern "C" int pt_trace_rays(pt_scene_t* scene, const float* origins, const floa
 	return pt_guarded("pt_trace_rays", [&]() { return pt_trace_rays_impl(scene, origins, directions, ray_count, triangle_indices, t_u_v, front); });
 }
 
-extern "C" int pt_evaluate_shading_data(pt_scene_t* scene, const pt_constants_t* constants, const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, uint32_t count, float* out_shading_data) {
-	return pt_guarded("pt_evaluate_shading_data", [&]() { return pt_evaluate_shading_data_impl(scene, constants, triangle_indices, barycentrics, front, out_dirs, count, out_shading_data); });
+extern "C" int pt_evaluate_shading_data(pt_scene_t* scene, const pt_constants_t* constants, const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, const float* footprints, uint32_t count, float* out_shading_data) {
+	return pt_guarded("pt_evaluate_shading_data", [&]() { return pt_evaluate_shading_data_impl(scene, constants, triangle_indices, barycentrics, front, out_dirs, footprints, count, out_shading_data); });
 }
 
 extern "C" int pt_trace_rays_no_alloc(pt_scene_t* scene, const float* device_origins, const float* device_directions, uint32_t ray_count, int32_t* device_triangle_indices, float* device_t_u_v, uint8_t* device_front) {

@@ -98,15 +98,8 @@ PT_FN void pt_seed_after_primary_ray(uint32_t x, uint32_t y, uint32_t frame_inde
 	pt_random(sx, sy);
 }
 
-PT_FN void pt_primary_ray(const PtConstants& c, uint32_t x, uint32_t y, uint32_t frame_index, uint32_t& sx, uint32_t& sy, v3* origin, v3* dir) {
-	sx = x ^ (frame_index << 16);
-	sy = y ^ ((frame_index + 237u) << 16);
-	v2 randoms = pt_random(sx, sy);
-	randoms.x = 2.0f * randoms.x - 1.0f;
-	randoms.y = 2.0f * randoms.y - 1.0f;
-	float scale = 0.9f * sqrtf(2.0f);
-	float jx = ((float) x + 0.5f) + scale * pt_erfinv(randoms.x);
-	float jy = ((float) y + 0.5f) + scale * pt_erfinv(randoms.y);
+// The camera ray through the point (jx, jy) of the image plane in pixels (pathtrace.frag.glsl:374-386)
+PT_FN void pt_camera_ray(const PtConstants& c, float jx, float jy, v3* origin, v3* dir) {
 	if (c.camera_type <= 1) {
 		v2 tc = mk2(jx * c.inv_viewport_size[0], jy * c.inv_viewport_size[1]);
 		*origin = pt_camera_ray_origin(tc, c.projection_to_world_space);
@@ -118,6 +111,29 @@ PT_FN void pt_primary_ray(const PtConstants& c, uint32_t x, uint32_t y, uint32_t
 		float factor_y = (c.camera_type == 3) ? 2.0f : 1.0f;
 		*dir = pt_to_world(f, pt_sample_hemisphere_spherical(mk2(jx * 1.0f * c.inv_viewport_size[0], jy * factor_y * c.inv_viewport_size[1])));
 	}
+}
+
+PT_FN float pt_length(v3 v) { return sqrtf(dot(v, v)); }
+
+// Seed, jittered position and camera ray of pixel (x, y). The ray's cone (see
+// "Ray cones" below) is what one pixel subtends: the rays one pixel to the
+// right and one pixel down tell how far apart neighbouring rays start and how
+// fast they diverge; the smaller of the two counts (the minor axis).
+PT_FN void pt_primary_ray(const PtConstants& c, uint32_t x, uint32_t y, uint32_t frame_index, uint32_t& sx, uint32_t& sy, v3* origin, v3* dir, float* cone_width, float* cone_spread) {
+	sx = x ^ (frame_index << 16);
+	sy = y ^ ((frame_index + 237u) << 16);
+	v2 randoms = pt_random(sx, sy);
+	randoms.x = 2.0f * randoms.x - 1.0f;
+	randoms.y = 2.0f * randoms.y - 1.0f;
+	float scale = 0.9f * sqrtf(2.0f);
+	float jx = ((float) x + 0.5f) + scale * pt_erfinv(randoms.x);
+	float jy = ((float) y + 0.5f) + scale * pt_erfinv(randoms.y);
+	pt_camera_ray(c, jx, jy, origin, dir);
+	v3 origin_right, dir_right, origin_down, dir_down;
+	pt_camera_ray(c, jx + 1.0f, jy, &origin_right, &dir_right);
+	pt_camera_ray(c, jx, jy + 1.0f, &origin_down, &dir_down);
+	*cone_width = fminf(pt_length(origin_right - *origin), pt_length(origin_down - *origin));
+	*cone_spread = fminf(pt_length(dir_right - *dir), pt_length(dir_down - *dir));
 }
 
 
@@ -147,9 +163,11 @@ PT_FN v3 pt_dequantize_normal(float ox, float oy) {
 
 
 // ---- texture(): shading_data.glsl:74-76 with the sampler of
-// src/main.c:864-873 (linear filtering, REPEAT addressing). Blocks are decoded
-// by hand with 8-bit integer palettes (once per scene, see below); filtering is
-// bilinear on mip 0 with float weights. ----
+// src/main.c:864-873 (linear min, mag and mip filters, REPEAT addressing, all
+// mip levels, anisotropy 16). Blocks are decoded by hand with 8-bit integer
+// palettes (once per scene, see below); filtering is trilinear with float
+// weights: bilinear on the two mip levels next to the level of detail, which
+// comes from the footprint of the path at the hit (pt_texture_lod_base()). ----
 
 // BC1 block (two RGB565 endpoints + 16 2-bit codes) -> 8-bit RGB of one texel
 PT_FN void pt_decode_bc1(uint32_t w0, uint32_t w1, uint32_t px, uint32_t py, uint32_t* r, uint32_t* g, uint32_t* b) {
@@ -188,21 +206,22 @@ PT_FN uint32_t pt_decode_bc4(uint32_t w0, uint32_t w1, uint32_t px, uint32_t py)
 // in the block-compressed original: the decode is exact integer arithmetic,
 // so sampling the decoded texels gives the same values as decoding per
 // sample, at a fifth of the instructions (shading is bound by them) and eight
-// times the memory of BC1, which 288 GB of HBM can afford. Mip 0 only.
+// times the memory of BC1, which 288 GB of HBM can afford. The mip levels of
+// a texture follow each other without gaps (pt_mip_texel_offset()).
 PT_FN uint64_t pt_texel_index(uint32_t log_w, uint32_t x, uint32_t y) {
 	return ((((uint64_t) (y >> 2) << (log_w - 2)) + (x >> 2)) << 4) + ((y & 3u) << 2) + (x & 3u);
 }
 
-// Texel (x, y) of mip 0 of a BC1 (formats 131, 132) or BC5 (141) texture
-PT_FN uint32_t pt_decode_texel(const uint8_t* mip_0, uint32_t log_w, uint32_t format, uint32_t x, uint32_t y) {
+// Texel (x, y) of one mip level, 2^log_w texels wide, of a BC1 (formats 131, 132) or BC5 (141) texture
+PT_FN uint32_t pt_decode_texel(const uint8_t* mip, uint32_t log_w, uint32_t format, uint32_t x, uint32_t y) {
 	uint64_t block = ((uint64_t) (y / 4) << (log_w - 2)) + x / 4;
 	if (format == 141) {
-		u32x4 w = *(const u32x4*) (mip_0 + block * 16);
+		u32x4 w = *(const u32x4*) (mip + block * 16);
 		uint32_t r = pt_decode_bc4(w.x, w.y, x & 3, y & 3);
 		uint32_t g = pt_decode_bc4(w.z, w.w, x & 3, y & 3);
 		return r | (g << 8);
 	}
-	u32x2 w = *(const u32x2*) (mip_0 + block * 8);
+	u32x2 w = *(const u32x2*) (mip + block * 8);
 	uint32_t r, g, b;
 	pt_decode_bc1(w.x, w.y, x & 3, y & 3, &r, &g, &b);
 	return r | (g << 8) | (b << 16);
@@ -223,10 +242,10 @@ PT_FN float pt_srgb_to_linear(const PtSceneView& s, uint32_t value) {
 #endif
 }
 
-PT_FN v3 pt_fetch_texel(const PtSceneView& s, u32x2 t, int32_t x, int32_t y) {
-	uint32_t log_w = t.y & 0xffu, log_h = (t.y >> 8) & 0xffu, format = t.y >> 16;
+PT_FN v3 pt_fetch_texel(const PtSceneView& s, u32x2 t, uint32_t level, int32_t x, int32_t y) {
+	uint32_t log_w = (t.y & 0xffu) - level, log_h = ((t.y >> 8) & 0xffu) - level, format = (t.y >> 16) & 0xffu;
 	uint32_t ux = (uint32_t) x & ((1u << log_w) - 1u), uy = (uint32_t) y & ((1u << log_h) - 1u);
-	const uint32_t* texels = (const uint32_t*) (s.texture_blob + ((uint64_t) t.x << 4));
+	const uint32_t* texels = (const uint32_t*) (s.texture_blob + ((uint64_t) t.x << 4)) + pt_mip_texel_offset(t.y & 0xffu, (t.y >> 8) & 0xffu, level);
 	uint32_t texel = texels[pt_texel_index(log_w, ux, uy)];
 	uint32_t r = texel & 0xffu, g = (texel >> 8) & 0xffu, b = (texel >> 16) & 0xffu;
 	if (format == 132)
@@ -234,17 +253,77 @@ PT_FN v3 pt_fetch_texel(const PtSceneView& s, u32x2 t, int32_t x, int32_t y) {
 	return mk3(pt_unorm8(r), pt_unorm8(g), pt_unorm8(b));
 }
 
-PT_FN v3 pt_sample_texture(const PtSceneView& s, uint32_t texture_index, v2 uv) {
-	u32x2 t = s.texture_table[texture_index];
-	float x = uv.x * (float) (1u << (t.y & 0xffu)) - 0.5f, y = uv.y * (float) (1u << ((t.y >> 8) & 0xffu)) - 0.5f;
+// Bilinear filtering of one mip level with REPEAT addressing
+PT_FN v3 pt_sample_texture_level(const PtSceneView& s, u32x2 t, uint32_t level, v2 uv) {
+	float x = uv.x * (float) (1u << ((t.y & 0xffu) - level)) - 0.5f, y = uv.y * (float) (1u << (((t.y >> 8) & 0xffu) - level)) - 0.5f;
 	float fx0 = floorf(x), fy0 = floorf(y);
 	float wx = x - fx0, wy = y - fy0;
 	int32_t x0 = (int32_t) fx0, y0 = (int32_t) fy0;
-	v3 t00 = pt_fetch_texel(s, t, x0, y0), t10 = pt_fetch_texel(s, t, x0 + 1, y0);
-	v3 t01 = pt_fetch_texel(s, t, x0, y0 + 1), t11 = pt_fetch_texel(s, t, x0 + 1, y0 + 1);
+	v3 t00 = pt_fetch_texel(s, t, level, x0, y0), t10 = pt_fetch_texel(s, t, level, x0 + 1, y0);
+	v3 t01 = pt_fetch_texel(s, t, level, x0, y0 + 1), t11 = pt_fetch_texel(s, t, level, x0 + 1, y0 + 1);
 	v3 top = t00 * (1.0f - wx) + t10 * wx;
 	v3 bottom = t01 * (1.0f - wx) + t11 * wx;
 	return top * (1.0f - wy) + bottom * wy;
+}
+
+// The level of detail of a texture lookup, up to the size of the texture.
+// The reference's texture() takes it from derivatives across a 2x2 pixel quad,
+// which are undefined once neighbouring paths have hit different surfaces;
+// here it follows from the footprint of the path itself (a ray cone): with
+// uv_area_2 and world_area_2 the doubled areas of the triangle in texture
+// coordinates and in the scene, a footprint of diameter `footprint` covers
+// uv_area_2 / world_area_2 * footprint^2 of the unit square of a texture and
+// 2^(log_w + log_h) times that in texels, so the level whose texels match it is
+//   lod = 0.5 * (log2(uv_area_2 / world_area_2 * footprint^2) + log_w + log_h)
+// The footprint is the one across the ray (the minor axis of its projection
+// onto the surface), as an anisotropic filter takes it; like the sampler's
+// maxAnisotropy of 16 (src/main.c:866-872) it grows only where the
+// projection is more than 16 times as long as wide (cos = |dot(normal,
+// direction)| < 1 / 16). Returns 0.5 * log2(...) without the size terms, or a
+// large negative number (level 0) where the triangle has no texture area.
+PT_FN float pt_texture_lod_base(float uv_area_2, float world_area_2, float footprint, float cos_out) {
+	float stretched = footprint * fmaxf(1.0f, 0.0625f / cos_out);
+	float covered = (uv_area_2 / world_area_2) * (stretched * stretched);
+	if (!(covered > 1.0e-30f))
+		return -1.0e9f;
+	return 0.5f * (pt_log(fminf(covered, 1.0e30f)) * 1.44269504088896341f);
+}
+
+// Trilinear filtering: the two mip levels around lod_base + (log_w + log_h) / 2,
+// clamped to the levels that the texture has
+PT_FN v3 pt_sample_texture(const PtSceneView& s, uint32_t texture_index, v2 uv, float lod_base) {
+	u32x2 t = s.texture_table[texture_index];
+	uint32_t last_level = (t.y >> 24) - 1u;
+	float lod = lod_base + 0.5f * (float) ((t.y & 0xffu) + ((t.y >> 8) & 0xffu));
+	lod = fminf(fmaxf(lod, 0.0f), (float) last_level);
+	float floor_lod = floorf(lod);
+	uint32_t level = (uint32_t) floor_lod;
+	float weight = lod - floor_lod;
+	v3 fine = pt_sample_texture_level(s, t, level, uv);
+	// At full weight the coarser level adds nothing (magnification and the last level end here)
+	if (!(weight > 0.0f))
+		return fine;
+	v3 coarse = pt_sample_texture_level(s, t, level + 1u, uv);
+	return fine * (1.0f - weight) + coarse * weight;
+}
+
+
+// ---- Ray cones: the footprint of a path for pt_texture_lod_base() ----
+// A ray carries the diameter of its footprint at its origin and the angle by
+// which the footprint widens per unit of distance. Both travel with the ray
+// as the upper halves of their floats (8 significant bits are plenty for a
+// level of detail) in the one word of the ray record that is free.
+PT_FN float pt_cone_quantize(float v) { return pt_as_float(pt_as_uint(v) & 0xffff0000u); }
+PT_FN float pt_pack_cone(float width, float spread) { return pt_as_float((pt_as_uint(width) & 0xffff0000u) | (pt_as_uint(spread) >> 16)); }
+PT_FN void pt_unpack_cone(float packed, float* width, float* spread) {
+	*width = pt_as_float(pt_as_uint(packed) & 0xffff0000u);
+	*spread = pt_as_float(pt_as_uint(packed) << 16);
+}
+// The widening that a bounce adds: half the angle of the cone whose solid
+// angle is the reciprocal of the density with which the direction was
+// sampled, 1 / sqrt(pi * density), at most 2; the sum is kept below 4
+PT_FN float pt_cone_spread_after_bounce(float spread, float density) {
+	return fminf(4.0f, spread + fminf(2.0f, 1.0f / sqrtf(PT_PI * density)));
 }
 
 
@@ -254,10 +333,17 @@ struct PtShadingData {
 	float lambert_out;
 	v3 emission, diffuse_albedo, fresnel_0;
 	float roughness;
+	// Not in the reference: the diameter of the path's footprint at pos
+	float footprint;
 };
 
 // ---- shading_data.glsl:51-103 ----
-PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants& c, uint32_t triangle_index, float bary_u, float bary_v, bool front, v3 out_dir) {
+// The ray that led here started at cone_origin with a footprint of diameter
+// cone_width that widens by cone_spread per unit of distance; that sets the
+// level of detail of the three texture lookups.
+PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants& c, uint32_t triangle_index, float bary_u, float bary_v, bool front, v3 out_dir,
+	v3 cone_origin, float cone_width, float cone_spread)
+{
 	PtShadingData s;
 	float barys[3] = { (1.0f - bary_u) - bary_v, bary_u, bary_v };
 	v3 poss[3];
@@ -284,15 +370,18 @@ PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants&
 	}
 	normal_geo = normalize(normal_geo);
 	uint32_t material = r3.x;
-	v3 base_color = pt_sample_texture(scene, 3 * material + 0, tc);
-	v3 specular = pt_sample_texture(scene, 3 * material + 1, tc);
-	v3 normal_tex = pt_sample_texture(scene, 3 * material + 2, tc);
+	// mat2(e1, e2) holds e1 and e2 as columns: [0][0] = e1.x, [1][0] = e2.x
+	v2 e1 = mk2(tcs[1].x - tcs[0].x, tcs[1].y - tcs[0].y), e2 = mk2(tcs[2].x - tcs[0].x, tcs[2].y - tcs[0].y);
+	v3 face = cross(poss[1] - poss[0], poss[2] - poss[0]);
+	s.footprint = fmaf(cone_spread, pt_length(s.pos - cone_origin), cone_width);
+	float lod_base = pt_texture_lod_base(fabsf(e1.x * e2.y - e2.x * e1.y), pt_length(face), s.footprint, fabsf(dot(normal_geo, out_dir)));
+	v3 base_color = pt_sample_texture(scene, 3 * material + 0, tc, lod_base);
+	v3 specular = pt_sample_texture(scene, 3 * material + 1, tc, lod_base);
+	v3 normal_tex = pt_sample_texture(scene, 3 * material + 2, tc, lod_base);
 	v3 normal_local;
 	normal_local.x = normal_tex.x * 2.0f - 1.0f;
 	normal_local.y = normal_tex.y * 2.0f - 1.0f;
 	normal_local.z = sqrtf(fmaxf(0.0f, (1.0f - normal_local.x * normal_local.x) - normal_local.y * normal_local.y));
-	// mat2(e1, e2) holds e1 and e2 as columns: [0][0] = e1.x, [1][0] = e2.x
-	v2 e1 = mk2(tcs[1].x - tcs[0].x, tcs[1].y - tcs[0].y), e2 = mk2(tcs[2].x - tcs[0].x, tcs[2].y - tcs[0].y);
 	v3 pre_tangent_0 = cross(normal_geo, poss[1] - poss[0]);
 	v3 pre_tangent_1 = cross(normal_geo, poss[0] - poss[2]);
 	v3 tangent_0 = pre_tangent_1 * e1.x + pre_tangent_0 * e2.x;
@@ -716,6 +805,7 @@ struct PtVertexResult {
 	v3 shadow_dir;
 	v3 shadow_weight; // throughput * brdf
 	float shadow_factor; // lambert / (light density + brdf density)
+	float next_cone;  // the cone of the extension ray, packed by pt_pack_cone()
 };
 
 // Shades vertex k (1-based) of a path. throughput, nee_throughput and the
@@ -724,7 +814,7 @@ struct PtVertexResult {
 // surface or the sky). hit_prim == 0xffffffff means the extension ray left
 // the scene.
 PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants& c, const PtLightCache& light_cache, int strategy, uint32_t path_length, uint32_t k,
-	uint32_t hit_prim, float hit_u, float hit_v, bool hit_front, v3 ray_dir,
+	uint32_t hit_prim, float hit_u, float hit_v, bool hit_front, v3 ray_origin, v3 ray_dir, float ray_cone,
 	v3& emitted, v3& throughput, v3& nee_throughput, uint32_t& sx, uint32_t& sy)
 {
 	PtVertexResult r;
@@ -732,6 +822,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 	r.shadow = false;
 	r.next_origin = r.next_dir = r.shadow_dir = r.shadow_weight = mk3(0.0f, 0.0f, 0.0f);
 	r.shadow_factor = 0.0f;
+	r.next_cone = 0.0f;
 	// In the NEE estimator emission is weighted by nee_throughput, in the
 	// others by throughput (pathtrace.frag.glsl:231,265,293,323)
 	bool next_event_estimation = strategy == PT_STRATEGY_NEE || strategy == PT_STRATEGY_NEE_TREE;
@@ -749,7 +840,9 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		emitted = emission_weight * emission;
 		return r;
 	}
-	PtShadingData s = pt_shading_data(scene, c, hit_prim, hit_u, hit_v, hit_front, -ray_dir);
+	float cone_width, cone_spread;
+	pt_unpack_cone(ray_cone, &cone_width, &cone_spread);
+	PtShadingData s = pt_shading_data(scene, c, hit_prim, hit_u, hit_v, hit_front, -ray_dir, ray_origin, cone_width, cone_spread);
 	emitted = emission_weight * s.emission;
 	r.next_origin = s.pos;
 	if (strategy == PT_STRATEGY_SPHERICAL || strategy == PT_STRATEGY_PSA) {
@@ -761,6 +854,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		float lambert_in = sampled_dir.z;
 		float density = (strategy == PT_STRATEGY_SPHERICAL) ? pt_hemisphere_spherical_density(sampled_dir.z) : pt_hemisphere_psa_density(sampled_dir.z);
 		throughput = throughput * ((pt_frostbite_brdf(s, r.next_dir) * lambert_in) / density);
+		r.next_cone = pt_pack_cone(s.footprint, pt_cone_spread_after_bounce(cone_spread, density));
 		r.continues = true;
 	}
 	else if (strategy == PT_STRATEGY_BRDF) {
@@ -771,6 +865,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		if (lambert_in <= 0.0f)
 			return r;
 		throughput = throughput * ((pt_frostbite_brdf(s, r.next_dir) * lambert_in) / density);
+		r.next_cone = pt_pack_cone(s.footprint, pt_cone_spread_after_bounce(cone_spread, density));
 		r.continues = true;
 	}
 	else {
@@ -808,6 +903,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		v3 brdf_lambert_1 = pt_frostbite_brdf(s, r.next_dir) * lambert_in_1;
 		nee_throughput = throughput * (brdf_lambert_1 / (light_density_1 + brdf_density_1));
 		throughput = throughput * (brdf_lambert_1 * (1.0f / brdf_density_1));
+		r.next_cone = pt_pack_cone(s.footprint, pt_cone_spread_after_bounce(cone_spread, brdf_density_1));
 		r.continues = true;
 	}
 	return r;

@@ -97,7 +97,7 @@ def lib():
         _lib.pt_trace_primary_rays.argtypes = [vp, C.POINTER(Constants), u32, vp, vp, vp]
         _lib.pt_trace_rays.argtypes = [vp, vp, vp, u32, vp, vp, vp]
         _lib.pt_trace_rays_no_alloc.argtypes = [vp, vp, vp, u32, vp, vp, vp]
-        _lib.pt_evaluate_shading_data.argtypes = [vp, C.POINTER(Constants), vp, vp, vp, vp, u32, vp]
+        _lib.pt_evaluate_shading_data.argtypes = [vp, C.POINTER(Constants), vp, vp, vp, vp, vp, u32, vp]
         _lib.pt_random_numbers.argtypes = [i32, u32, u32, u32, u32, vp]
     return _lib
 
@@ -216,13 +216,14 @@ class Scene:
         _check(lib().pt_trace_rays(self.handle, _ptr(o), _ptr(d), len(o), _ptr(tri), _ptr(tuv), _ptr(front)), "pt_trace_rays")
         return tri, tuv, front
 
-    def evaluate_shading_data(self, constants, triangles, barys, front, out_dirs):
+    def evaluate_shading_data(self, constants, triangles, barys, front, out_dirs, footprints=None):
         triangles = np.ascontiguousarray(triangles, np.int32).reshape(-1)
         barys = np.ascontiguousarray(barys, np.float32).reshape(-1, 2)
         front = np.ascontiguousarray(front, np.uint8).reshape(-1)
         out_dirs = np.ascontiguousarray(out_dirs, np.float32).reshape(-1, 3)
         out = np.zeros((len(triangles), 20), np.float32)
-        _check(lib().pt_evaluate_shading_data(self.handle, C.byref(constants), _ptr(triangles), _ptr(barys), _ptr(front), _ptr(out_dirs), len(triangles), _ptr(out)), "pt_evaluate_shading_data")
+        _check(lib().pt_evaluate_shading_data(self.handle, C.byref(constants), _ptr(triangles), _ptr(barys), _ptr(front), _ptr(out_dirs),
+                                                  None if footprints is None else _ptr(np.ascontiguousarray(footprints, np.float32).reshape(-1)), len(triangles), _ptr(out)), "pt_evaluate_shading_data")
         return out
 
 

@@ -45,7 +45,8 @@ def lib():
         _lib.emu_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.emu_render.restype = C.c_uint64
         _lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
-        _lib.emu_shading_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.emu_primary_cones.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        _lib.emu_shading_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.emu_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
         _lib.emu_log.restype = C.c_float
         _lib.emu_log.argtypes = [C.c_float]
@@ -56,6 +57,16 @@ def lib():
 
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def _footprints(footprints, count):
+    """Pointer to count float32 footprints, or NULL for none (which the callee reads as zeros)."""
+    if footprints is None:
+        return None
+    array = np.ascontiguousarray(footprints, np.float32).reshape(-1)
+    assert len(array) == count
+    _footprints.keep = array
+    return array.ctypes.data_as(C.c_void_p)
 
 
 class EmuScene:
@@ -102,6 +113,13 @@ class EmuScene:
         lib().emu_trace_rays(self.handle, _ptr(o), _ptr(d), len(o), _ptr(tri), _ptr(tuv), _ptr(front), _ptr(visits))
         return tri, tuv, front, visits
 
+    def primary_cones(self, constants, frame_index):
+        width, height = int(constants.viewport_size[0]), int(constants.viewport_size[1])
+        widths = np.zeros((height, width), np.float32)
+        spreads = np.zeros((height, width), np.float32)
+        lib().emu_primary_cones(C.byref(constants), frame_index, _ptr(widths), _ptr(spreads))
+        return widths, spreads
+
     def primary_hits(self, constants, frame_index):
         w, h = int(constants.viewport_size[0]), int(constants.viewport_size[1])
         tri = np.zeros((h, w), np.int32)
@@ -120,7 +138,7 @@ class EmuScene:
         rays = lib().emu_render(self.handle, C.byref(constants), strategy, path_length, emission_material_index, first_frame_index, frame_count, frame_stride, int(accumulate), _ptr(accum))
         return accum, rays
 
-    def shading_data(self, constants, triangles, barys, front, out_dirs, emission_material_index=None):
+    def shading_data(self, constants, triangles, barys, front, out_dirs, emission_material_index=None, footprints=None):
         triangles = np.ascontiguousarray(triangles, np.int32).reshape(-1)
         barys = np.ascontiguousarray(barys, np.float32).reshape(-1, 2)
         front = np.ascontiguousarray(front, np.uint8).reshape(-1)
@@ -128,5 +146,5 @@ class EmuScene:
         if emission_material_index is None:
             emission_material_index = self.scene.emission_material_index
         out = np.zeros((len(triangles), 20), np.float32)
-        lib().emu_shading_data(self.handle, C.byref(constants), emission_material_index, _ptr(triangles), _ptr(barys), _ptr(front), _ptr(out_dirs), len(triangles), _ptr(out))
+        lib().emu_shading_data(self.handle, C.byref(constants), emission_material_index, _ptr(triangles), _ptr(barys), _ptr(front), _ptr(out_dirs), _footprints(footprints, len(triangles)), len(triangles), _ptr(out))
         return out

@@ -164,23 +164,26 @@ EmuScene* emu_create_scene(uint64_t material_count, uint64_t triangle_count, con
 		s->srgb[i] = (float) ((c <= 0.04045) ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
 	}
 	s->textures.resize(texture_count ? texture_count : 1);
-	// As pt_create_scene(): mip 0 of every texture decoded into tiled 8-bit texels
+	// As pt_create_scene(): every mip level of every texture decoded into tiled 8-bit texels, level after level
 	for (uint32_t i = 0; i != texture_count; ++i) {
 		const EmuTexture& t = textures[i];
 		PtTexture& d = s->textures[i];
-		d.width = t.width; d.height = t.height; d.format = t.format; d.mip_count = 1;
-		size_t offset = s->blob.size();
-		d.mip_offsets[0] = offset;
-		s->blob.resize(offset + (size_t) t.width * t.height * 4);
-		u32x2 packed = pt_pack_texture(d);
-		uint32_t log_w = packed.y & 0xffu;
+		d.width = t.width; d.height = t.height; d.format = t.format; d.mip_count = t.mip_count;
 		uint32_t block = (t.format == 141) ? 16 : 8;
-		std::vector<uint8_t> aligned((size_t) ((t.width + 3) / 4) * ((t.height + 3) / 4) * block + 16);
-		memcpy(aligned.data(), t.payload + t.mip_offsets[0], aligned.size() - 16);
-		uint32_t* texels = (uint32_t*) &s->blob[offset];
-		for (uint32_t y = 0; y != t.height; ++y)
-			for (uint32_t x = 0; x != t.width; ++x)
-				texels[pt_texel_index(log_w, x, y)] = pt_decode_texel(aligned.data(), log_w, t.format, x, y);
+		for (uint32_t m = 0; m != t.mip_count; ++m) {
+			uint32_t mw = t.width >> m, mh = t.height >> m;
+			size_t offset = s->blob.size();
+			d.mip_offsets[m] = offset;
+			s->blob.resize(offset + (size_t) mw * mh * 4);
+			uint32_t log_w = 0;
+			while ((1u << log_w) < mw) ++log_w;
+			std::vector<uint8_t> aligned((size_t) (mw / 4) * (mh / 4) * block + 16);
+			memcpy(aligned.data(), t.payload + t.mip_offsets[m], aligned.size() - 16);
+			uint32_t* texels = (uint32_t*) &s->blob[offset];
+			for (uint32_t y = 0; y != mh; ++y)
+				for (uint32_t x = 0; x != mw; ++x)
+					texels[pt_texel_index(log_w, x, y)] = pt_decode_texel(aligned.data(), log_w, t.format, x, y);
+		}
 	}
 	s->blob.resize(s->blob.size() + 16);
 	s->texture_table.resize(s->textures.size());
@@ -333,13 +336,26 @@ void emu_primary_hits(EmuScene* s, const PtConstants* c, uint32_t frame_index, i
 	for (uint32_t y = 0; y != h; ++y) for (uint32_t x = 0; x != w; ++x) {
 		uint32_t sx, sy;
 		v3 o, d;
-		pt_primary_ray(*c, x, y, frame_index, sx, sy, &o, &d);
+		float cone_width, cone_spread;
+		pt_primary_ray(*c, x, y, frame_index, sx, sy, &o, &d, &cone_width, &cone_spread);
 		EmuStack stack;
 		PtHit hit = pt_trace_closest<false>(s->nodes.data(), s->tris.data(), s->n, o, d, 1.0e-3f, 1e38f, stack, NULL);
 		size_t i = (size_t) y * w + x;
 		triangles[i] = (int32_t) hit.prim;
 		barys[2 * i] = hit.u; barys[2 * i + 1] = hit.v;
 		front[i] = hit.front;
+	}
+}
+
+void emu_primary_cones(const PtConstants* c, uint32_t frame_index, float* widths, float* spreads) {
+	uint32_t w = (uint32_t) c->viewport_size[0], h = (uint32_t) c->viewport_size[1];
+	for (uint32_t y = 0; y != h; ++y) for (uint32_t x = 0; x != w; ++x) {
+		uint32_t sx, sy;
+		v3 o, d;
+		float cone_width, cone_spread;
+		pt_primary_ray(*c, x, y, frame_index, sx, sy, &o, &d, &cone_width, &cone_spread);
+		// What travels with the ray
+		pt_unpack_cone(pt_pack_cone(cone_width, cone_spread), &widths[(size_t) y * w + x], &spreads[(size_t) y * w + x]);
 	}
 }
 
@@ -357,7 +373,9 @@ uint64_t emu_render(EmuScene* s, const PtConstants* c, int strategy, uint32_t pa
 		for (uint32_t f = 0; f != frame_count; ++f) {
 			uint32_t sx, sy;
 			v3 o, d;
-			pt_primary_ray(*c, x, y, first_frame + f * frame_stride, sx, sy, &o, &d);
+			float cone_width, cone_spread;
+			pt_primary_ray(*c, x, y, first_frame + f * frame_stride, sx, sy, &o, &d, &cone_width, &cone_spread);
+			float cone = pt_pack_cone(cone_width, cone_spread);
 			v3 throughput = mk3(1, 1, 1), nee = mk3(1, 1, 1), radiance = mk3(0, 0, 0);
 			for (uint32_t k = 1; k <= path_length; ++k) {
 				EmuStack stack;
@@ -367,7 +385,7 @@ uint64_t emu_render(EmuScene* s, const PtConstants* c, int strategy, uint32_t pa
 				float cached_importances[8];
 				PtLightCache light_cache = { cached_importances, 1, 8 };
 				v3 emitted;
-				PtVertexResult r = pt_shade_vertex(scene, *c, light_cache, strategy, path_length, k, hit.prim, hit.u, hit.v, hit.front, d, emitted, throughput, nee, sx, sy);
+				PtVertexResult r = pt_shade_vertex(scene, *c, light_cache, strategy, path_length, k, hit.prim, hit.u, hit.v, hit.front, o, d, cone, emitted, throughput, nee, sx, sy);
 				radiance = radiance + emitted;
 				if (r.shadow) {
 					EmuStack sstack;
@@ -380,7 +398,7 @@ uint64_t emu_render(EmuScene* s, const PtConstants* c, int strategy, uint32_t pa
 					radiance = radiance + (r.shadow_weight * emission) * r.shadow_factor;
 				}
 				if (!r.continues) break;
-				o = r.next_origin; d = r.next_dir;
+				o = r.next_origin; d = r.next_dir; cone = r.next_cone;
 			}
 			if (f == 0 && !accumulate) { pixel[0] = radiance.x; pixel[1] = radiance.y; pixel[2] = radiance.z; pixel[3] = 1.0f; }
 			else { pixel[0] += radiance.x; pixel[1] += radiance.y; pixel[2] += radiance.z; }
@@ -389,11 +407,12 @@ uint64_t emu_render(EmuScene* s, const PtConstants* c, int strategy, uint32_t pa
 	return rays;
 }
 
-void emu_shading_data(EmuScene* s, const PtConstants* c, uint32_t emission_material_index, const int32_t* triangles, const float* barys, const uint8_t* front, const float* out_dirs, uint32_t count, float* out) {
+void emu_shading_data(EmuScene* s, const PtConstants* c, uint32_t emission_material_index, const int32_t* triangles, const float* barys, const uint8_t* front, const float* out_dirs, const float* footprints, uint32_t count, float* out) {
 	s->emission_material_index = emission_material_index;
 	PtSceneView scene = s->view();
 	for (uint32_t i = 0; i != count; ++i) {
-		PtShadingData d = pt_shading_data(scene, *c, (uint32_t) triangles[i], barys[2 * i], barys[2 * i + 1], front[i] != 0, mk3(out_dirs[3 * i], out_dirs[3 * i + 1], out_dirs[3 * i + 2]));
+		PtShadingData d = pt_shading_data(scene, *c, (uint32_t) triangles[i], barys[2 * i], barys[2 * i + 1], front[i] != 0, mk3(out_dirs[3 * i], out_dirs[3 * i + 1], out_dirs[3 * i + 2]),
+			mk3(0.0f, 0.0f, 0.0f), footprints ? footprints[i] : 0.0f, 0.0f);
 		float* o = &out[20 * (size_t) i];
 		o[0] = d.pos.x; o[1] = d.pos.y; o[2] = d.pos.z; o[3] = d.normal.x; o[4] = d.normal.y; o[5] = d.normal.z;
 		o[6] = d.out_dir.x; o[7] = d.out_dir.y; o[8] = d.out_dir.z; o[9] = d.lambert_out;

@@ -25,7 +25,10 @@ def quantize_positions(points):
     return np.stack([word0, word1], 1), factor, summand
 
 
-def random_texture(rng, size, fmt, mips=1):
+def random_texture(rng, size, fmt, mips=None):
+    """Random blocks on every level; mips=None gives the full chain down to 4x4 like the reference's converter."""
+    if mips is None:
+        mips = max(1, int(np.log2(size)) - 1)
     block = 16 if fmt == 141 else 8
     payloads, extents, offsets, offset = [], [], [], 0
     for m in range(mips):
@@ -38,8 +41,23 @@ def random_texture(rng, size, fmt, mips=1):
     return formats.Texture(size, size, fmt, mips, extents, np.array(offsets, np.uint64), np.concatenate(payloads))
 
 
-def triangle_soup(seed=1, triangle_count=4000, material_count=3, extent=10.0, size=0.6, texture_size=32, emission_fraction=0.05):
-    """Random small triangles in a cube, random block-compressed textures, first material emits."""
+def noise_texture(rng, size, fmt):
+    """White noise with a proper mip chain: every level is the Gaussian-filtered level 0, compressed by the
+    authoring tool of this repository (path_tracer_amd/tools/vkt.py), as a converter would write it."""
+    import os
+    import tempfile
+    from path_tracer_amd.tools import vkt
+    image = rng.uniform(0.0, 1.0, (size, size, 2 if fmt == 141 else 3))
+    with tempfile.TemporaryDirectory() as directory:
+        path = os.path.join(directory, "noise.vkt")
+        vkt.write_vkt(path, image, fmt)
+        return formats.load_vkt(path)
+
+
+def triangle_soup(seed=1, triangle_count=4000, material_count=3, extent=10.0, size=0.6, texture_size=32, emission_fraction=0.05, filtered_mips=False):
+    """Random small triangles in a cube, random block-compressed textures, first material emits. With filtered_mips
+    the textures are noise whose coarser levels are filtered from level 0; otherwise every level is random blocks
+    of its own (more distinct values per level, but no level is the mean of the one below)."""
     rng = np.random.default_rng(seed)
     centers = rng.uniform(-extent / 2, extent / 2, (triangle_count, 1, 3))
     verts = centers + rng.normal(scale=size, size=(triangle_count, 3, 3))
@@ -54,8 +72,9 @@ def triangle_soup(seed=1, triangle_count=4000, material_count=3, extent=10.0, si
     materials[rng.random(triangle_count) < emission_fraction] = 0
     names = ["_emission"] + ["material_%d" % i for i in range(1, material_count)]
     textures = []
+    make_texture = noise_texture if filtered_mips else random_texture
     for _ in range(material_count):
-        textures += [random_texture(rng, texture_size, 132), random_texture(rng, texture_size, 131), random_texture(rng, texture_size, 141)]
+        textures += [make_texture(rng, texture_size, 132), make_texture(rng, texture_size, 131), make_texture(rng, texture_size, 141)]
     return formats.Scene(names, triangle_count, factor, summand, positions, normals_uvs, materials, textures)
 
 

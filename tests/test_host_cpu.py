@@ -310,3 +310,22 @@ def test_texture_file_with_wrapping_mip_header_is_refused(tmp_path):
     huge = bytearray(source)
     struct.pack_into("<Q", huge, 24, 2 ** 40)
     assert not loads(bytes(huge))
+
+
+def test_textures_with_inconsistent_mip_chains_are_refused():
+    """Levels end at an extent of 4 and level m holds (width >> m) x (height >> m) texels: anything else is refused
+    on the host, before the payloads are sent to the GPU."""
+    from tests import synthetic
+    scene = synthetic.triangle_soup(seed=3, triangle_count=10, material_count=1, texture_size=16)
+
+    def create(textures):
+        return hip_api.Scene(1, scene.dequantization_factor, scene.dequantization_summand, scene.positions, scene.normals_uvs, scene.materials, textures)
+
+    good = [(t.width, t.height, t.format, [t.payload[int(t.mip_offsets[m]):int(t.mip_offsets[m]) + t.mip_extents[m][2]] for m in range(t.mip_count)]) for t in scene.textures]
+    assert [len(t[3]) for t in good] == [3, 3, 3]
+    too_many = [(w, h, f, mips + [mips[-1]]) for w, h, f, mips in good]
+    with pytest.raises(hip_api.PtError):
+        create(too_many)
+    wrong_size = [(w, h, f, [mips[0], mips[1][:-8], mips[2]]) for w, h, f, mips in good]
+    with pytest.raises(hip_api.PtError):
+        create(wrong_size)

@@ -151,6 +151,44 @@ int pt_read_accumulation(pt_scene_t* scene, float* rgba, uint32_t* out_sample_co
 void* pt_get_accumulation_device_pointer(pt_scene_t* scene);
 int pt_set_sample_count(pt_scene_t* scene, uint32_t sample_count);
 
+/* Several GPUs of one node. No counterpart in the reference, which renders
+ * on one GPU. Samples are independent given pixel and frame index
+ * (src/shaders/pathtrace.frag.glsl:368): a context holds a replica of the
+ * scene on every GPU of device_ids, GPU g of n renders the frame indices
+ * first + g, first + g + n, ... into its own accumulation target, and
+ * pt_context_reduce() sums the targets over xGMI (one RCCL reduction) into
+ * the target of the first GPU. The union of the slices is exactly the set of
+ * frames a single GPU would render; only the order of the float additions
+ * differs. The scene arguments are those of pt_create_scene(); lights,
+ * settings and render targets are set for all replicas at once, with the
+ * meaning of the pt_set_*() / pt_create_render_targets() calls above.
+ * pt_context_scene(context, i) is the replica on GPU device_ids[i], for
+ * calls per GPU (statistics, BVH info) and, with i = 0 after
+ * pt_context_reduce(), for pt_read_accumulation(). A context with one GPU
+ * renders the same bits as that GPU's scene alone. */
+typedef struct pt_context pt_context_t;
+int pt_create_context(pt_context_t** out_context, const int* device_ids, uint32_t device_count, const pt_scene_header_t* header,
+	const uint32_t* positions, const uint16_t* normals_and_tex_coords, const uint8_t* material_indices,
+	const pt_texture_desc_t* textures, uint32_t texture_count);
+void pt_destroy_context(pt_context_t* context);
+uint32_t pt_context_device_count(const pt_context_t* context);
+pt_scene_t* pt_context_scene(pt_context_t* context, uint32_t index);
+int pt_context_set_lights(pt_context_t* context, const float* lights, uint32_t count);
+int pt_context_set_light_sampling(pt_context_t* context, int light_sampling);
+int pt_context_set_render_settings(pt_context_t* context, int sampling_strategy, uint32_t path_length, uint32_t emission_material_index);
+int pt_context_create_render_targets(pt_context_t* context, uint32_t width, uint32_t height);
+/* pt_render_samples() for sample_count frames in total, shared out as
+ * described above. With accumulate 0 the targets of all GPUs start over. */
+int pt_context_render_samples(pt_context_t* context, const pt_constants_t* constants, uint32_t first_frame_index, uint32_t sample_count, int accumulate);
+int pt_context_synchronize(pt_context_t* context);
+/* Waits for the GPUs, then sums their targets into that of the first one
+ * (alpha stays 1, its sample count becomes the total) and clears the others,
+ * so that rendering may go on and be reduced again without counting
+ * anything twice. pt_context_last_reduce_ms() is the wall time the last
+ * reduction took (sum, alpha, clears), for throughput reports. */
+int pt_context_reduce(pt_context_t* context);
+double pt_context_last_reduce_ms(const pt_context_t* context);
+
 /* Counters and timings since the last reset. Ray counts are the numbers of
  * extension and shadow rays actually traced (queue sizes). Node and triangle
  * visits are only counted while profiling is enabled. Kernel times are sums

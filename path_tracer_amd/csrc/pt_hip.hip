@@ -29,6 +29,7 @@
 #include <rocprim/rocprim.hpp>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 #include <exception>
 #include <new>
 #include <vector>
@@ -57,6 +58,16 @@ static_assert(sizeof(float) * PT_LIGHT_CACHE_SIZE * PT_SHADE_BLOCK <= 64 * 1024,
 
 #define PT_CHECK(call) do { hipError_t pt_err_ = (call); if (pt_err_ != hipSuccess) { \
 	printf("HIP error %s at %s:%d (%s).\n", hipGetErrorString(pt_err_), __FILE__, __LINE__, #call); return 1; } } while (0)
+
+// Makes a GPU current for an entry point and forgets the HIP runtime's
+// "last error" of this thread: other users of the runtime in the same process
+// (RCCL and PyTorch probe optional features and leave such errors behind)
+// must not make this library's own checks of hipGetLastError() fail.
+static hipError_t pt_select_device(int device_index) {
+	hipError_t result = hipSetDevice(device_index);
+	(void) hipGetLastError();
+	return result;
+}
 
 // Runs the body of an entry point of the C ABI. The callers are C: no
 // exception (std::bad_alloc of a std::vector sized by the caller's data, for
@@ -1056,7 +1067,7 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 			return 1;
 		}
 	}
-	if (hipSetDevice(device_index) != hipSuccess) {
+	if (pt_select_device(device_index) != hipSuccess) {
 		printf("Failed to select GPU %d.\n", device_index);
 		return 1;
 	}
@@ -1240,7 +1251,7 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 static int pt_set_lights_impl(pt_scene_t* s, const float* lights, uint32_t count) {
 	if (!s || (count && !lights))
 		return 1;
-	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(pt_select_device(s->device));
 	PT_CHECK(hipStreamSynchronize(s->stream));
 	// The light tree is built on the host: it is small (64 bytes per light)
 	// and changes only here
@@ -1298,7 +1309,7 @@ static int pt_create_render_targets_impl(pt_scene_t* s, uint32_t width, uint32_t
 		printf("Unsupported render target extent %ux%u.\n", width, height);
 		return 1;
 	}
-	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(pt_select_device(s->device));
 	PT_CHECK(hipStreamSynchronize(s->stream));
 	pt_collect(s);
 	pt_free_render_targets(s);
@@ -1470,7 +1481,7 @@ static int pt_render_samples_impl(pt_scene_t* s, const pt_constants_t* constants
 	}
 	if (sample_count == 0)
 		return 0;
-	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(pt_select_device(s->device));
 	uint32_t frames_per_batch = s->max_frames_per_batch < sample_count ? s->max_frames_per_batch : sample_count;
 	if (pt_reserve_wavefront(s, s->frame_layout.paths_per_frame * frames_per_batch))
 		return 1;
@@ -1515,7 +1526,7 @@ static int pt_check_device_errors(pt_scene* s) {
 static int pt_synchronize_impl(pt_scene_t* s) {
 	if (!s)
 		return 1;
-	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(pt_select_device(s->device));
 	PT_CHECK(hipStreamSynchronize(s->stream));
 	pt_collect(s);
 	return pt_check_device_errors(s);
@@ -1604,7 +1615,7 @@ static int pt_trace_primary_rays_impl(pt_scene_t* s, const pt_constants_t* const
 		printf("pt_trace_primary_rays() needs render targets matching the viewport size in the constants.\n");
 		return 1;
 	}
-	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(pt_select_device(s->device));
 	if (pt_reserve_wavefront(s, s->frame_layout.paths_per_frame))
 		return 1;
 	PtBatch batch = s->frame_layout;
@@ -1651,7 +1662,7 @@ static int pt_trace_rays_impl(pt_scene_t* s, const float* origins, const float* 
 		return 1;
 	if (ray_count == 0)
 		return 0;
-	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(pt_select_device(s->device));
 	PT_CHECK(hipStreamSynchronize(s->stream));
 	f32x4* d_origins = NULL; f32x4* d_directions = NULL; int32_t* d_triangles = NULL; float* d_tuv = NULL; uint8_t* d_front = NULL;
 	uint32_t* d_control = NULL; // ray count followed by 8 fetch counters
@@ -1717,7 +1728,7 @@ static int pt_trace_rays_no_alloc_impl(pt_scene_t* s, const float* device_origin
 	}
 	if (ray_count == 0)
 		return 0;
-	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(pt_select_device(s->device));
 	// The address that hipGetSymbolAddress() returned for this device, never the array's name
 	unsigned char* scratch = s->no_alloc_scratch;
 	uint32_t* control = (uint32_t*) scratch;
@@ -1760,7 +1771,7 @@ static int pt_evaluate_shading_data_impl(pt_scene_t* s, const pt_constants_t* co
 			return 1;
 		}
 	}
-	PT_CHECK(hipSetDevice(s->device));
+	PT_CHECK(pt_select_device(s->device));
 	PT_CHECK(hipStreamSynchronize(s->stream));
 	int32_t* d_triangles = NULL; float* d_barycentrics = NULL; uint8_t* d_front = NULL; float* d_dirs = NULL; float* d_footprints = NULL; float* d_out = NULL;
 	int result = 1;
@@ -1792,7 +1803,7 @@ extern "C" int pt_random_numbers(int device_index, uint32_t x, uint32_t y, uint3
 		return 1;
 	if (draw_count == 0)
 		return 0;
-	PT_CHECK(hipSetDevice(device_index));
+	PT_CHECK(pt_select_device(device_index));
 	float* d_out = NULL;
 	if (pt_alloc(&d_out, 2 * (uint64_t) draw_count))
 		return 1;
@@ -1805,6 +1816,282 @@ extern "C" int pt_random_numbers(int device_index, uint32_t x, uint32_t y, uint3
 	}
 	return 0;
 }
+
+
+// ---------------------------------------------------------------- several GPUs
+//
+// Samples are independent given pixel and frame index
+// (src/shaders/pathtrace.frag.glsl:368), so a context replicates the scene on
+// every GPU, GPU g of n renders the frame indices first + g, first + g + n, ...
+// into its own target and one RCCL reduction over xGMI sums the targets into
+// that of the first GPU. Nothing else is exchanged. RCCL is loaded when the
+// first context is created, so hosts with one GPU do not depend on it.
+
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+struct pt_rccl_api {
+	void* library;
+	ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*);
+	ncclResult_t (*CommDestroy)(ncclComm_t);
+	ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t);
+	ncclResult_t (*GroupStart)();
+	ncclResult_t (*GroupEnd)();
+	const char* (*GetErrorString)(ncclResult_t);
+};
+static pt_rccl_api pt_rccl;
+
+static int pt_load_rccl() {
+	if (pt_rccl.library)
+		return 0;
+	void* library = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+	if (!library)
+		library = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+	if (!library) {
+		printf("Failed to load RCCL (librccl.so.1), which sums the render targets of several GPUs: %s.\n", dlerror());
+		return 1;
+	}
+	pt_rccl_api api;
+	api.library = library;
+	api.CommInitAll = (decltype(api.CommInitAll)) dlsym(library, "ncclCommInitAll");
+	api.CommDestroy = (decltype(api.CommDestroy)) dlsym(library, "ncclCommDestroy");
+	api.Reduce = (decltype(api.Reduce)) dlsym(library, "ncclReduce");
+	api.GroupStart = (decltype(api.GroupStart)) dlsym(library, "ncclGroupStart");
+	api.GroupEnd = (decltype(api.GroupEnd)) dlsym(library, "ncclGroupEnd");
+	api.GetErrorString = (decltype(api.GetErrorString)) dlsym(library, "ncclGetErrorString");
+	if (!api.CommInitAll || !api.CommDestroy || !api.Reduce || !api.GroupStart || !api.GroupEnd || !api.GetErrorString) {
+		printf("The RCCL library lacks one of the functions ncclCommInitAll, ncclCommDestroy, ncclReduce, ncclGroupStart, ncclGroupEnd, ncclGetErrorString.\n");
+		dlclose(library);
+		return 1;
+	}
+	pt_rccl = api;
+	return 0;
+}
+
+#define PT_RCCL_CHECK(call) do { ncclResult_t pt_nccl_ = (call); if (pt_nccl_ != ncclSuccess) { \
+	printf("RCCL error %s at %s:%d (%s).\n", pt_rccl.GetErrorString(pt_nccl_), __FILE__, __LINE__, #call); return 1; } } while (0)
+
+struct pt_context {
+	std::vector<pt_scene*> scenes;
+	std::vector<int> devices;
+	std::vector<ncclComm_t> comms;
+	double reduce_ms; // wall time of the last pt_context_reduce()
+};
+
+// After the sum the alpha channel of the first GPU's target holds the number
+// of GPUs whose target was not empty; the reference keeps it at 1 (src/main.c:1015-1017)
+__global__ void __launch_bounds__(PT_BLOCK) k_reset_alpha(f32x4* accum, uint32_t pixel_count) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i < pixel_count)
+		accum[i].w = 1.0f;
+}
+
+static void pt_destroy_context_impl(pt_context* c) {
+	if (!c)
+		return;
+	for (size_t i = 0; i != c->comms.size(); ++i) {
+		if (c->comms[i]) {
+			hipSetDevice(c->devices[i]);
+			pt_rccl.CommDestroy(c->comms[i]);
+		}
+	}
+	for (size_t i = 0; i != c->scenes.size(); ++i)
+		pt_destroy_scene(c->scenes[i]);
+	delete c;
+}
+
+static int pt_create_context_impl(pt_context** out_context, const int* device_ids, uint32_t device_count, const pt_scene_header_t* header,
+	const uint32_t* positions, const uint16_t* normals_and_tex_coords, const uint8_t* material_indices, const pt_texture_desc_t* textures, uint32_t texture_count)
+{
+	if (!device_ids || device_count == 0 || device_count > PT_MAX_DEVICES) {
+		printf("pt_create_context() needs between 1 and %d GPU indices.\n", PT_MAX_DEVICES);
+		return 1;
+	}
+	for (uint32_t i = 0; i != device_count; ++i) {
+		for (uint32_t j = 0; j != i; ++j) {
+			if (device_ids[i] == device_ids[j]) {
+				printf("pt_create_context() got GPU %d twice.\n", device_ids[i]);
+				return 1;
+			}
+		}
+	}
+	if (pt_load_rccl())
+		return 1;
+	pt_context* c = new pt_context();
+	*out_context = c;
+	c->reduce_ms = 0.0;
+	c->devices.assign(device_ids, device_ids + device_count);
+	c->comms.assign(device_count, (ncclComm_t) NULL);
+	for (uint32_t i = 0; i != device_count; ++i) {
+		pt_scene* scene = NULL;
+		if (pt_create_scene(&scene, device_ids[i], header, positions, normals_and_tex_coords, material_indices, textures, texture_count)) {
+			printf("Failed to replicate the scene on GPU %d.\n", device_ids[i]);
+			return 1;
+		}
+		c->scenes.push_back(scene);
+	}
+	PT_RCCL_CHECK(pt_rccl.CommInitAll(c->comms.data(), (int) device_count, c->devices.data()));
+	return 0;
+}
+
+// The frames that GPU g of n renders out of sample_count frames from first on: (first, count, stride)
+static void pt_context_slice(uint32_t g, uint32_t n, uint32_t first_frame_index, uint32_t sample_count, uint32_t* out_first, uint32_t* out_count) {
+	*out_first = first_frame_index + g;
+	*out_count = (sample_count > g) ? (sample_count - g + n - 1) / n : 0;
+}
+
+static int pt_context_render_samples_impl(pt_context* c, const pt_constants_t* constants, uint32_t first_frame_index, uint32_t sample_count, int accumulate) {
+	if (!c || !constants)
+		return 1;
+	const uint32_t n = (uint32_t) c->scenes.size();
+	std::vector<uint32_t> done(n, 0u);
+	// The GPUs take turns, one batch each, so that all of them have work
+	// queued while the host is still handing out the rest
+	bool any = true;
+	while (any) {
+		any = false;
+		for (uint32_t g = 0; g != n; ++g) {
+			pt_scene* s = c->scenes[g];
+			uint32_t first, count;
+			pt_context_slice(g, n, first_frame_index, sample_count, &first, &count);
+			if (count == 0 && !accumulate && done[g] == 0) {
+				// This GPU has no frame of a fresh accumulation: its target must not keep an old one
+				if (!s->accum) {
+					printf("pt_context_render_samples() needs render targets; call pt_context_create_render_targets() first.\n");
+					return 1;
+				}
+				PT_CHECK(pt_select_device(s->device));
+				PT_CHECK(hipMemsetAsync(s->accum, 0, sizeof(f32x4) * (uint64_t) s->width * s->height, s->stream));
+				s->sample_count = 0;
+				done[g] = 1;
+				continue;
+			}
+			if (done[g] >= count)
+				continue;
+			uint32_t frames = count - done[g];
+			uint32_t batch = s->max_frames_per_batch ? s->max_frames_per_batch : 1;
+			if (frames > batch)
+				frames = batch;
+			if (pt_render_samples(s, constants, first + done[g] * n, frames, n, (accumulate || done[g] != 0) ? 1 : 0))
+				return 1;
+			done[g] += frames;
+			any = any || done[g] < count;
+		}
+	}
+	return 0;
+}
+
+static int pt_context_reduce_impl(pt_context* c) {
+	if (!c)
+		return 1;
+	const uint32_t n = (uint32_t) c->scenes.size();
+	pt_scene* root = c->scenes[0];
+	if (!root->accum) {
+		printf("pt_context_reduce() needs render targets; call pt_context_create_render_targets() first.\n");
+		return 1;
+	}
+	const uint64_t pixel_count = (uint64_t) root->width * root->height;
+	for (uint32_t g = 0; g != n; ++g) {
+		if (c->scenes[g]->width != root->width || c->scenes[g]->height != root->height || !c->scenes[g]->accum) {
+			printf("The render targets of GPU %d do not match those of GPU %d.\n", c->devices[g], c->devices[0]);
+			return 1;
+		}
+	}
+	struct timespec begin, end;
+	for (uint32_t g = 0; g != n; ++g)
+		if (pt_synchronize(c->scenes[g]))
+			return 1;
+	clock_gettime(CLOCK_MONOTONIC, &begin);
+	// One sum over xGMI: every GPU contributes its target, the first receives the total
+	PT_RCCL_CHECK(pt_rccl.GroupStart());
+	for (uint32_t g = 0; g != n; ++g) {
+		pt_scene* s = c->scenes[g];
+		PT_CHECK(pt_select_device(s->device));
+		PT_RCCL_CHECK(pt_rccl.Reduce(s->accum, s->accum, 4 * pixel_count, ncclFloat, ncclSum, 0, c->comms[g], s->stream));
+	}
+	PT_RCCL_CHECK(pt_rccl.GroupEnd());
+	uint32_t total_samples = 0;
+	for (uint32_t g = 0; g != n; ++g) {
+		pt_scene* s = c->scenes[g];
+		total_samples += s->sample_count;
+		PT_CHECK(pt_select_device(s->device));
+		if (g == 0)
+			hipLaunchKernelGGL(k_reset_alpha, dim3(pt_grid(pixel_count)), dim3(PT_BLOCK), 0, s->stream, s->accum, (uint32_t) pixel_count);
+		else {
+			// What this GPU rendered is part of the total now; it starts over,
+			// so that another reduction after more frames counts nothing twice
+			PT_CHECK(hipMemsetAsync(s->accum, 0, sizeof(f32x4) * pixel_count, s->stream));
+			s->sample_count = 0;
+		}
+	}
+	root->sample_count = total_samples;
+	for (uint32_t g = 0; g != n; ++g) {
+		PT_CHECK(hipSetDevice(c->scenes[g]->device));
+		PT_CHECK(hipStreamSynchronize(c->scenes[g]->stream));
+	}
+	clock_gettime(CLOCK_MONOTONIC, &end);
+	c->reduce_ms = 1.0e3 * (double) (end.tv_sec - begin.tv_sec) + 1.0e-6 * (double) (end.tv_nsec - begin.tv_nsec);
+	PT_CHECK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int pt_create_context(pt_context_t** out_context, const int* device_ids, uint32_t device_count, const pt_scene_header_t* header,
+	const uint32_t* positions, const uint16_t* normals_and_tex_coords, const uint8_t* material_indices, const pt_texture_desc_t* textures, uint32_t texture_count)
+{
+	if (!out_context)
+		return 1;
+	*out_context = NULL;
+	int result = pt_guarded("pt_create_context", [&]() { return pt_create_context_impl(out_context, device_ids, device_count, header, positions, normals_and_tex_coords, material_indices, textures, texture_count); });
+	if (result && *out_context) {
+		pt_destroy_context_impl(*out_context);
+		*out_context = NULL;
+	}
+	return result;
+}
+
+extern "C" void pt_destroy_context(pt_context_t* context) {
+	pt_guarded("pt_destroy_context", [&]() { pt_destroy_context_impl(context); return 0; });
+}
+
+extern "C" uint32_t pt_context_device_count(const pt_context_t* context) { return context ? (uint32_t) context->scenes.size() : 0u; }
+
+extern "C" pt_scene_t* pt_context_scene(pt_context_t* context, uint32_t index) {
+	return (context && index < context->scenes.size()) ? context->scenes[index] : NULL;
+}
+
+// Applies one call to the scene of every GPU
+template <typename Call>
+static int pt_context_for_each(pt_context_t* context, Call call) {
+	if (!context)
+		return 1;
+	for (size_t i = 0; i != context->scenes.size(); ++i)
+		if (call(context->scenes[i]))
+			return 1;
+	return 0;
+}
+
+extern "C" int pt_context_set_lights(pt_context_t* context, const float* lights, uint32_t count) {
+	return pt_context_for_each(context, [&](pt_scene* s) { return pt_set_lights(s, lights, count); });
+}
+extern "C" int pt_context_set_light_sampling(pt_context_t* context, int light_sampling) {
+	return pt_context_for_each(context, [&](pt_scene* s) { return pt_set_light_sampling(s, light_sampling); });
+}
+extern "C" int pt_context_set_render_settings(pt_context_t* context, int sampling_strategy, uint32_t path_length, uint32_t emission_material_index) {
+	return pt_context_for_each(context, [&](pt_scene* s) { return pt_set_render_settings(s, sampling_strategy, path_length, emission_material_index); });
+}
+extern "C" int pt_context_create_render_targets(pt_context_t* context, uint32_t width, uint32_t height) {
+	return pt_context_for_each(context, [&](pt_scene* s) { return pt_create_render_targets(s, width, height); });
+}
+extern "C" int pt_context_synchronize(pt_context_t* context) {
+	return pt_context_for_each(context, [&](pt_scene* s) { return pt_synchronize(s); });
+}
+extern "C" int pt_context_render_samples(pt_context_t* context, const pt_constants_t* constants, uint32_t first_frame_index, uint32_t sample_count, int accumulate) {
+	return pt_guarded("pt_context_render_samples", [&]() { return pt_context_render_samples_impl(context, constants, first_frame_index, sample_count, accumulate); });
+}
+extern "C" int pt_context_reduce(pt_context_t* context) {
+	return pt_guarded("pt_context_reduce", [&]() { return pt_context_reduce_impl(context); });
+}
+extern "C" double pt_context_last_reduce_ms(const pt_context_t* context) { return context ? context->reduce_ms : 0.0; }
 
 
 // ---------------------------------------------------------------- C ABI

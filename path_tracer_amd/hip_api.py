@@ -18,6 +18,9 @@ EXPORTED_SYMBOLS = [
     "pt_create_scene", "pt_destroy_scene", "pt_set_lights", "pt_set_light_sampling", "pt_set_render_settings", "pt_create_render_targets",
     "pt_render_samples", "pt_synchronize", "pt_read_accumulation", "pt_get_accumulation_device_pointer",
     "pt_set_sample_count", "pt_set_instrumentation", "pt_get_statistics", "pt_reset_statistics", "pt_get_bvh_info",
+    "pt_create_context", "pt_destroy_context", "pt_context_device_count", "pt_context_scene", "pt_context_set_lights",
+    "pt_context_set_light_sampling", "pt_context_set_render_settings", "pt_context_create_render_targets",
+    "pt_context_render_samples", "pt_context_synchronize", "pt_context_reduce", "pt_context_last_reduce_ms",
     "pt_trace_primary_rays", "pt_trace_rays", "pt_trace_rays_no_alloc", "pt_evaluate_shading_data", "pt_random_numbers",
 ]
 
@@ -99,6 +102,22 @@ def lib():
         _lib.pt_trace_rays_no_alloc.argtypes = [vp, vp, vp, u32, vp, vp, vp]
         _lib.pt_evaluate_shading_data.argtypes = [vp, C.POINTER(Constants), vp, vp, vp, vp, vp, u32, vp]
         _lib.pt_random_numbers.argtypes = [i32, u32, u32, u32, u32, vp]
+        _lib.pt_create_context.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), u32, C.POINTER(SceneHeader), vp, vp, vp, C.POINTER(TextureDesc), u32]
+        _lib.pt_destroy_context.argtypes = [vp]
+        _lib.pt_destroy_context.restype = None
+        _lib.pt_context_device_count.argtypes = [vp]
+        _lib.pt_context_device_count.restype = u32
+        _lib.pt_context_scene.argtypes = [vp, u32]
+        _lib.pt_context_scene.restype = vp
+        _lib.pt_context_set_lights.argtypes = [vp, vp, u32]
+        _lib.pt_context_set_light_sampling.argtypes = [vp, i32]
+        _lib.pt_context_set_render_settings.argtypes = [vp, i32, u32, u32]
+        _lib.pt_context_create_render_targets.argtypes = [vp, u32, u32]
+        _lib.pt_context_render_samples.argtypes = [vp, C.POINTER(Constants), u32, u32, i32]
+        _lib.pt_context_synchronize.argtypes = [vp]
+        _lib.pt_context_reduce.argtypes = [vp]
+        _lib.pt_context_last_reduce_ms.argtypes = [vp]
+        _lib.pt_context_last_reduce_ms.restype = C.c_double
     return _lib
 
 

@@ -94,7 +94,17 @@ void init_render_settings(render_settings_t* settings) {
 }
 
 /* src/main.c:687-704 */
+static int create_lit_scene_on(lit_scene_t* lit_scene, const int* device_indices, uint32_t device_count, bool use_context, const char* scene_path, const char* textures_path, const char* lights_path);
+
 int create_lit_scene_from_paths(lit_scene_t* lit_scene, int device_index, const char* scene_path, const char* textures_path, const char* lights_path) {
+	return create_lit_scene_on(lit_scene, &device_index, 1, false, scene_path, textures_path, lights_path);
+}
+
+int create_lit_scene_from_paths_devices(lit_scene_t* lit_scene, const int* device_indices, uint32_t device_count, const char* scene_path, const char* textures_path, const char* lights_path) {
+	return create_lit_scene_on(lit_scene, device_indices, device_count, true, scene_path, textures_path, lights_path);
+}
+
+static int create_lit_scene_on(lit_scene_t* lit_scene, const int* device_indices, uint32_t device_count, bool use_context, const char* scene_path, const char* textures_path, const char* lights_path) {
 	memset(lit_scene, 0, sizeof(*lit_scene));
 	FILE* file = lights_path ? fopen(lights_path, "rb") : NULL;
 	if (file) {
@@ -110,10 +120,14 @@ int create_lit_scene_from_paths(lit_scene_t* lit_scene, int device_index, const 
 	}
 	else
 		lit_scene->spherical_lights = calloc(1, sizeof(float) * 4);
-	int result = load_scene(&lit_scene->scene, device_index, scene_path, textures_path);
+	int result = use_context ? load_scene_devices(&lit_scene->scene, device_indices, device_count, scene_path, textures_path)
+		: load_scene(&lit_scene->scene, device_indices[0], scene_path, textures_path);
 	if (!result) {
 		printf("Loaded %lu triangles and %lu materials from %s.\n", (unsigned long) lit_scene->scene.header.triangle_count, (unsigned long) lit_scene->scene.header.material_count, scene_path);
-		result = pt_set_lights(lit_scene->scene.device_scene, &lit_scene->spherical_lights[0][0], lit_scene->spherical_light_count);
+		if (lit_scene->scene.device_context)
+			result = pt_context_set_lights(lit_scene->scene.device_context, &lit_scene->spherical_lights[0][0], lit_scene->spherical_light_count);
+		else
+			result = pt_set_lights(lit_scene->scene.device_scene, &lit_scene->spherical_lights[0][0], lit_scene->spherical_light_count);
 	}
 	if (result)
 		free_lit_scene(lit_scene);
@@ -131,7 +145,17 @@ static char* join_path(const char* root, const char* path) {
 }
 
 /* src/main.c:679-704 */
+static int create_lit_scene_spec_on(lit_scene_t* lit_scene, const int* device_indices, uint32_t device_count, bool use_context, const scene_spec_t* scene_spec, const char* data_root);
+
 int create_lit_scene(lit_scene_t* lit_scene, int device_index, const scene_spec_t* scene_spec, const char* data_root) {
+	return create_lit_scene_spec_on(lit_scene, &device_index, 1, false, scene_spec, data_root);
+}
+
+int create_lit_scene_devices(lit_scene_t* lit_scene, const int* device_indices, uint32_t device_count, const scene_spec_t* scene_spec, const char* data_root) {
+	return create_lit_scene_spec_on(lit_scene, device_indices, device_count, true, scene_spec, data_root);
+}
+
+static int create_lit_scene_spec_on(lit_scene_t* lit_scene, const int* device_indices, uint32_t device_count, bool use_context, const scene_spec_t* scene_spec, const char* data_root) {
 	const char* scene_path;
 	const char* textures_path;
 	const char* lights_path;
@@ -143,7 +167,7 @@ int create_lit_scene(lit_scene_t* lit_scene, int device_index, const scene_spec_
 	char* scene = join_path(data_root, scene_path);
 	char* textures = join_path(data_root, textures_path);
 	char* lights = join_path(data_root, lights_path);
-	int result = create_lit_scene_from_paths(lit_scene, device_index, scene, textures, lights);
+	int result = create_lit_scene_on(lit_scene, device_indices, device_count, use_context, scene, textures, lights);
 	free(scene);
 	free(textures);
 	free(lights);
@@ -158,17 +182,31 @@ void free_lit_scene(lit_scene_t* lit_scene) {
 }
 
 int apply_render_settings(lit_scene_t* lit_scene, const render_settings_t* settings) {
+	if (lit_scene->scene.device_context)
+		return pt_context_set_render_settings(lit_scene->scene.device_context, (int) settings->sampling_strategy, settings->path_length, lit_scene->scene.emission_material_index);
 	return pt_set_render_settings(lit_scene->scene.device_scene, (int) settings->sampling_strategy, settings->path_length, lit_scene->scene.emission_material_index);
 }
 
 int set_light_sampling(lit_scene_t* lit_scene, int light_sampling) {
+	if (lit_scene->scene.device_context)
+		return pt_context_set_light_sampling(lit_scene->scene.device_context, light_sampling);
 	return pt_set_light_sampling(lit_scene->scene.device_scene, light_sampling);
+}
+
+int reduce_render_targets(lit_scene_t* lit_scene) {
+	if (!lit_scene->scene.device_context)
+		return 0;
+	if (pt_context_reduce(lit_scene->scene.device_context)) {
+		printf("Failed to sum the render targets of %u GPUs.\n", pt_context_device_count(lit_scene->scene.device_context));
+		return 1;
+	}
+	return 0;
 }
 
 /* src/main.c:519-560 */
 int create_render_targets(render_targets_t* render_targets, lit_scene_t* lit_scene, uint32_t width, uint32_t height) {
 	memset(render_targets, 0, sizeof(*render_targets));
-	if (pt_create_render_targets(lit_scene->scene.device_scene, width, height)) {
+	if (lit_scene->scene.device_context ? pt_context_create_render_targets(lit_scene->scene.device_context, width, height) : pt_create_render_targets(lit_scene->scene.device_scene, width, height)) {
 		printf("Failed to create render targets with resolution %ux%u.\n", width, height);
 		return 1;
 	}
@@ -224,7 +262,9 @@ int render_frames(scene_spec_t* scene_spec, lit_scene_t* lit_scene, render_targe
 	/* The reference increments the frame index before each frame, so the
 	   first of these frames uses frame_index + 1 */
 	uint32_t first_frame_index = scene_spec->frame_index + 1;
-	if (pt_render_samples(lit_scene->scene.device_scene, &constants, first_frame_index, frame_count, 1, render_targets->accum_frame_count != 0)) {
+	int accumulate = render_targets->accum_frame_count != 0;
+	if (lit_scene->scene.device_context ? pt_context_render_samples(lit_scene->scene.device_context, &constants, first_frame_index, frame_count, accumulate)
+		: pt_render_samples(lit_scene->scene.device_scene, &constants, first_frame_index, frame_count, 1, accumulate)) {
 		printf("Failed to render %u frames.\n", frame_count);
 		return 1;
 	}
@@ -239,7 +279,7 @@ int save_screenshot(const char* file_path, image_file_format_t format, lit_scene
 	size_t pixel_count = (size_t) width * height;
 	float* floats = malloc(pixel_count * 4 * sizeof(float));
 	uint32_t accum_frame_count = 0;
-	if (pt_read_accumulation(lit_scene->scene.device_scene, floats, &accum_frame_count)) {
+	if (reduce_render_targets(lit_scene) || pt_read_accumulation(lit_scene->scene.device_scene, floats, &accum_frame_count)) {
 		printf("Failed to copy the off-screen render target to host memory for taking a screenshot.\n");
 		free(floats);
 		return 1;

@@ -76,6 +76,9 @@ typedef enum {
 typedef struct {
 	scene_file_header_t header;
 	pt_scene_t* device_scene;
+	/* Not in the reference: set when the scene is replicated on several GPUs
+	 * (load_scene_devices()); device_scene is then its replica on the first */
+	pt_context_t* device_context;
 	/* Index of the material called _emission, 0 if there is none
 	 * (src/main.c:936-939) */
 	uint32_t emission_material_index;
@@ -83,6 +86,9 @@ typedef struct {
 
 /* src/scene.h:104; device_index replaces the Vulkan device */
 int load_scene(scene_t* scene, int device_index, const char* file_path, const char* texture_path);
+/* The same for several GPUs of one node, which share out the frames among
+ * themselves (no counterpart in the reference) */
+int load_scene_devices(scene_t* scene, const int* device_indices, uint32_t device_count, const char* file_path, const char* texture_path);
 void free_scene(scene_t* scene);
 
 /* ---- src/textures.h: textures are read into host memory and handed to
@@ -189,6 +195,14 @@ void init_render_settings(render_settings_t* settings);
  * paths that get_scene_file() reports when the spec variant is used) */
 int create_lit_scene_from_paths(lit_scene_t* lit_scene, int device_index, const char* scene_path, const char* textures_path, const char* lights_path);
 int create_lit_scene(lit_scene_t* lit_scene, int device_index, const scene_spec_t* scene_spec, const char* data_root);
+/* The same on several GPUs (no counterpart in the reference): every function
+ * below that takes the lit scene then acts on all of them, render_frames()
+ * shares the frames out and the screenshot functions sum the targets first */
+int create_lit_scene_from_paths_devices(lit_scene_t* lit_scene, const int* device_indices, uint32_t device_count, const char* scene_path, const char* textures_path, const char* lights_path);
+int create_lit_scene_devices(lit_scene_t* lit_scene, const int* device_indices, uint32_t device_count, const scene_spec_t* scene_spec, const char* data_root);
+/* Sums the render targets of all GPUs into that of the first one; a no-op
+ * for a lit scene on one GPU. save_screenshot() and save_display_image() call it. */
+int reduce_render_targets(lit_scene_t* lit_scene);
 void free_lit_scene(lit_scene_t* lit_scene);
 /* Applies render_settings_t and the light list to the device scene (what
  * create_scene_subpass() bakes into shader defines at src/main.c:936-949) */

@@ -19,8 +19,26 @@ static char* cat_strings(const char* const* parts, uint32_t part_count) {
 	return result;
 }
 
+static int load_scene_on(scene_t* scene, const int* device_indices, uint32_t device_count, bool use_context, const char* file_path, const char* texture_path);
+
 int load_scene(scene_t* scene, int device_index, const char* file_path, const char* texture_path) {
+	return load_scene_on(scene, &device_index, 1, false, file_path, texture_path);
+}
+
+/* load_scene() for a list of GPUs: the scene is replicated through a
+ * pt_context_t (frames are shared out among the GPUs and summed over xGMI,
+ * also when the list has one entry); device_scene is the replica on the
+ * first GPU. */
+int load_scene_devices(scene_t* scene, const int* device_indices, uint32_t device_count, const char* file_path, const char* texture_path) {
+	return load_scene_on(scene, device_indices, device_count, true, file_path, texture_path);
+}
+
+static int load_scene_on(scene_t* scene, const int* device_indices, uint32_t device_count, bool use_context, const char* file_path, const char* texture_path) {
 	memset(scene, 0, sizeof(*scene));
+	if (!device_indices || device_count == 0) {
+		printf("Loading the scene file at %s needs at least one GPU.\n", file_path);
+		return 1;
+	}
 	FILE* file = fopen(file_path, "rb");
 	if (!file) {
 		printf("Failed to open the scene file at %s. Please check path and permissions.\n", file_path);
@@ -120,7 +138,14 @@ int load_scene(scene_t* scene, int device_index, const char* file_path, const ch
 		pt_scene_header_t device_header = { .material_count = header->material_count, .triangle_count = header->triangle_count };
 		memcpy(device_header.dequantization_factor, header->dequantization_factor, sizeof(float) * 3);
 		memcpy(device_header.dequantization_summand, header->dequantization_summand, sizeof(float) * 3);
-		int create_result = pt_create_scene(&scene->device_scene, device_index, &device_header, positions, normals_and_tex_coords, material_indices, descs, (uint32_t) texture_count);
+		int create_result;
+		if (!use_context)
+			create_result = pt_create_scene(&scene->device_scene, device_indices[0], &device_header, positions, normals_and_tex_coords, material_indices, descs, (uint32_t) texture_count);
+		else {
+			create_result = pt_create_context(&scene->device_context, device_indices, device_count, &device_header, positions, normals_and_tex_coords, material_indices, descs, (uint32_t) texture_count);
+			if (!create_result)
+				scene->device_scene = pt_context_scene(scene->device_context, 0);
+		}
 		free(descs);
 		if (create_result) {
 			printf("Failed to create ray-tracing acceleration structures for the scene file at %s.\n", file_path);
@@ -144,7 +169,11 @@ int load_scene(scene_t* scene, int device_index, const char* file_path, const ch
 
 /* src/scene.c:407-420 */
 void free_scene(scene_t* scene) {
-	pt_destroy_scene(scene->device_scene);
+	/* The replicas of a context belong to the context */
+	if (scene->device_context)
+		pt_destroy_context(scene->device_context);
+	else
+		pt_destroy_scene(scene->device_scene);
 	if (scene->header.material_names)
 		for (uint64_t i = 0; i != scene->header.material_count; ++i)
 			free(scene->header.material_names[i]);

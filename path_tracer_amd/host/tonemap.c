@@ -84,7 +84,7 @@ int save_display_image(const char* file_path, image_file_format_t format, lit_sc
 	float* floats = malloc(pixel_count * 4 * sizeof(float));
 	uint8_t* ldr = malloc(pixel_count * 3);
 	uint32_t accum_frame_count = 0;
-	int result = pt_read_accumulation(lit_scene->scene.device_scene, floats, &accum_frame_count);
+	int result = reduce_render_targets(lit_scene) || pt_read_accumulation(lit_scene->scene.device_scene, floats, &accum_frame_count);
 	if (result)
 		printf("Failed to copy the off-screen render target to host memory.\n");
 	else {

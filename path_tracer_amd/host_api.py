@@ -19,6 +19,7 @@ EXPORTED_SYMBOLS = [
     "get_world_to_view_space", "get_view_to_projection_space", "get_world_to_projection_space",
     "load_scene", "free_scene", "load_textures", "free_textures",
     "get_scene_file", "quicksave", "quickload", "init_scene_spec", "init_render_settings",
+    "load_scene_devices", "create_lit_scene_from_paths_devices", "create_lit_scene_devices", "reduce_render_targets",
     "create_lit_scene_from_paths", "create_lit_scene", "free_lit_scene", "apply_render_settings", "set_light_sampling",
     "create_render_targets", "write_constant_buffer", "render_frames", "save_screenshot", "write_hdr", "write_png",
 ]
@@ -50,7 +51,7 @@ class SceneFileHeader(C.Structure):
 
 
 class HostScene(C.Structure):
-    _fields_ = [("header", SceneFileHeader), ("device_scene", C.c_void_p), ("emission_material_index", C.c_uint32)]
+    _fields_ = [("header", SceneFileHeader), ("device_scene", C.c_void_p), ("device_context", C.c_void_p), ("emission_material_index", C.c_uint32)]
 
 
 class LitScene(C.Structure):
@@ -122,6 +123,9 @@ def lib():
         _lib.init_render_settings.restype = None
         _lib.create_lit_scene_from_paths.argtypes = [C.POINTER(LitScene), i32, C.c_char_p, C.c_char_p, C.c_char_p]
         _lib.create_lit_scene.argtypes = [C.POINTER(LitScene), i32, C.POINTER(SceneSpec), C.c_char_p]
+        _lib.create_lit_scene_devices.argtypes = [C.POINTER(LitScene), C.POINTER(C.c_int), u32, C.POINTER(SceneSpec), C.c_char_p]
+        _lib.create_lit_scene_from_paths_devices.argtypes = [C.POINTER(LitScene), C.POINTER(C.c_int), u32, C.c_char_p, C.c_char_p, C.c_char_p]
+        _lib.reduce_render_targets.argtypes = [C.POINTER(LitScene)]
         _lib.free_lit_scene.argtypes = [C.POINTER(LitScene)]
         _lib.free_lit_scene.restype = None
         _lib.apply_render_settings.argtypes = [C.POINTER(LitScene), C.POINTER(RenderSettings)]
@@ -171,13 +175,19 @@ def scene_file_paths(scene_file):
 class Renderer:
     """The host objects of one GPU: lit scene, render settings, render targets (what app_t holds in the reference)."""
 
-    def __init__(self, spec: SceneSpec, data_root, device=0, width=1280, height=1024, sampling_strategy=hip_api.SAMPLING_STRATEGY_NEE, path_length=4):
+    def __init__(self, spec: SceneSpec, data_root, device=0, width=1280, height=1024, sampling_strategy=hip_api.SAMPLING_STRATEGY_NEE, path_length=4, devices=None):
+        """devices: a list of GPU indices makes the C host replicate the scene on all of them (a pt_context_t); frames
+        are then shared out among them and summed over xGMI before the accumulation is read."""
         self.spec = SceneSpec.from_buffer_copy(bytes(spec))
         self.lit_scene = LitScene()
         self.targets = RenderTargets()
         self.settings = RenderSettings(sampling_strategy, path_length)
         self._alive = False
-        _check(lib().create_lit_scene(C.byref(self.lit_scene), device, C.byref(self.spec), os.fsencode(data_root)), "create_lit_scene")
+        if devices is None:
+            _check(lib().create_lit_scene(C.byref(self.lit_scene), device, C.byref(self.spec), os.fsencode(data_root)), "create_lit_scene")
+        else:
+            ids = (C.c_int * len(devices))(*devices)
+            _check(lib().create_lit_scene_devices(C.byref(self.lit_scene), ids, len(devices), C.byref(self.spec), os.fsencode(data_root)), "create_lit_scene_devices")
         self._alive = True
         _check(lib().apply_render_settings(C.byref(self.lit_scene), C.byref(self.settings)), "apply_render_settings")
         _check(lib().create_render_targets(C.byref(self.targets), C.byref(self.lit_scene), width, height), "create_render_targets")
@@ -206,10 +216,22 @@ class Renderer:
     def render_frames(self, frame_count):
         _check(lib().render_frames(C.byref(self.spec), C.byref(self.lit_scene), C.byref(self.targets), frame_count), "render_frames")
 
+    @property
+    def device_context(self):
+        return C.c_void_p(self.lit_scene.scene.device_context) if self.lit_scene.scene.device_context else None
+
     def synchronize(self):
-        _check(hip_api.lib().pt_synchronize(self.device_scene), "pt_synchronize")
+        if self.device_context:
+            _check(hip_api.lib().pt_context_synchronize(self.device_context), "pt_context_synchronize")
+        else:
+            _check(hip_api.lib().pt_synchronize(self.device_scene), "pt_synchronize")
+
+    def reduce(self):
+        """Sums the targets of all GPUs into the first one's (nothing to do on one GPU)."""
+        _check(lib().reduce_render_targets(C.byref(self.lit_scene)), "reduce_render_targets")
 
     def read_accumulation(self):
+        self.reduce()
         rgba = np.zeros((self.height, self.width, 4), np.float32)
         count = C.c_uint32()
         _check(hip_api.lib().pt_read_accumulation(self.device_scene, rgba.ctypes.data_as(C.c_void_p), C.byref(count)), "pt_read_accumulation")

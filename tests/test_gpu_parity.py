@@ -297,7 +297,14 @@ def test_display_image_and_jpg(tmp_path):
         renderer.save_display_image(path)
         expected = np.zeros((48, 64, 3), np.uint8)
         host_api.lib().tonemap_image(expected.ctypes.data_as(C.c_void_p), accum.ctypes.data_as(C.c_void_p), 48 * 64, renderer.spec.exposure, count, tonemapper)
-        assert (np.asarray(Image.open(path)) == expected).all() and expected.max() > 100
+        saved = np.asarray(Image.open(path))
+        assert (saved == expected).all() and expected.max() > 100
+        # Independently of the host's own tonemapper: the shader's formulas in float64 followed by the sRGB encoding
+        from tests.test_host_cpu import _tonemap_expected
+        linear = np.array([_tonemap_expected(pixel, renderer.spec.exposure, count, tonemapper) for pixel in accum.reshape(-1, 4)]).reshape(48, 64, 3)
+        linear = np.clip(linear, 0.0, 1.0)
+        reference = np.where(linear <= 0.0031308, 12.92 * linear, 1.055 * linear ** (1 / 2.4) - 0.055) * 255.0
+        assert np.abs(saved.astype(np.float64) - reference).max() <= 0.5 + 1e-3
     jpg = str(tmp_path / "s.jpg")
     renderer.save_screenshot(jpg)
     ldr = np.clip(accum[..., :3] * (1.0 / count), 0, 1)

@@ -17,7 +17,7 @@ from tests.paths import DATA, DATA_ROOT, ROOT
 def declared_functions(header_path):
     text = open(header_path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|void\*?|void)\s+\*?\s*(pt_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|void\*?|void|uint32_t|double|pt_scene_t\*)\s+\*?\s*(pt_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_hip_library_exports_every_declared_symbol():

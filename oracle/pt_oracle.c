@@ -408,8 +408,19 @@ static hit_t trace_closest(const oracle_scene_t* s, vec3 origin, vec3 dir, float
 		float t0x = (n->lo[0] - origin.x) * idir.x, t1x = (n->hi[0] - origin.x) * idir.x;
 		float t0y = (n->lo[1] - origin.y) * idir.y, t1y = (n->hi[1] - origin.y) * idir.y;
 		float t0z = (n->lo[2] - origin.z) * idir.z, t1z = (n->hi[2] - origin.z) * idir.z;
-		float tnear = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fmaxf(fminf(t0z, t1z), tmin));
-		float tfar = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fminf(fmaxf(t0z, t1z), hit.t));
+		/* The rounding of these differences, and of those in the triangle
+		   test, grows with the distance between box and ray origin: the test
+		   gives way by 2^-21 of the largest such distance (the padding of the
+		   boxes only covers rays that start near the scene) */
+		float reach = 0.0f;
+		for (int j = 0; j != 3; ++j) {
+			float o = (j == 0) ? origin.x : ((j == 1) ? origin.y : origin.z);
+			reach = fmaxf(reach, fmaxf(fabsf(n->lo[j] - o), fabsf(n->hi[j] - o)));
+		}
+		float give = reach * 4.76837158203125e-07f;
+		float gx = give * fabsf(idir.x), gy = give * fabsf(idir.y), gz = give * fabsf(idir.z);
+		float tnear = fmaxf(fmaxf(fminf(t0x, t1x) - gx, fminf(t0y, t1y) - gy), fmaxf(fminf(t0z, t1z) - gz, tmin));
+		float tfar = fminf(fminf(fmaxf(t0x, t1x) + gx, fmaxf(t0y, t1y) + gy), fminf(fmaxf(t0z, t1z) + gz, hit.t));
 		if (!(tnear <= tfar))
 			continue;
 		if (n->count) {

@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtCons
 // trace_ray() of pathtrace.frag.glsl:181-199 up to the hit record.
 // Persistent waves: the grid is sized to the chip, not to the queue.
 template <bool COUNT_VISITS>
-__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_extension(PtTraceArgs a) {
+__global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_trace_extension(PtTraceArgs a) {
 	__shared__ PtTraceLds lds;
 	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
 	PtRayQueue queue;
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_extension(PtTraceArgs 
 
 // trace_ray_emission() of pathtrace.frag.glsl:203-219 and the MIS sum at :338
 template <bool COUNT_VISITS>
-__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_shadow(PtTraceArgs a) {
+__global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_trace_shadow(PtTraceArgs a) {
 	__shared__ PtTraceLds lds;
 	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
 	PtRayQueue queue;
@@ -552,7 +552,7 @@ struct PtUserRayArgs {
 	uint8_t* front;
 };
 
-__global__ void __launch_bounds__(PT_TRACE_BLOCK) k_trace_user_rays(PtUserRayArgs a) {
+__global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_trace_user_rays(PtUserRayArgs a) {
 	__shared__ PtTraceLds lds;
 	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
 	PtRayQueue queue;

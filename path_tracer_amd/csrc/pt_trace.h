@@ -71,6 +71,22 @@ PT_FN void pt_intersect_triangle(PtHit& hit, const PtRayShear& r, v3 origin, v3 
 	}
 }
 
+// How far, in scene units, the box test has to err on the side of a hit. Both
+// the slab test and the triangle test subtract the ray origin from scene
+// coordinates first; the rounding of that difference grows with the distance
+// between the two, not with the size of the scene, so for a ray that starts
+// far outside (an orthographic camera, a caller's own rays) no padding of the
+// boxes that is fixed at build time can cover it. The triangle test shears
+// the other two axes by the coordinate along the ray's dominant axis, which
+// carries that rounding across axes, hence the largest of the three
+// distances to the node (d: node origin minus ray origin; a node spans at most
+// 255 grid steps of size s per axis beyond its origin) counts for all axes:
+// 2^-21 of it, eight units in the last place.
+PT_FN float pt_box_test_slack(float dx, float dy, float dz, float sx, float sy, float sz) {
+	float reach = fmaxf(fmaxf(fabsf(dx), fabsf(dy)), fabsf(dz)) + 255.0f * fmaxf(fmaxf(sx, sy), sz);
+	return reach * 4.76837158203125e-07f;
+}
+
 PT_FN float pt_byte_to_float(uint32_t word, int byte) { return (float) ((word >> (8 * byte)) & 0xffu); }
 
 // Stack must provide push(u32x2), pop() and empty(). An entry is a group of
@@ -116,7 +132,12 @@ PT_FN PtHit pt_trace_closest(const PtNode* nodes, const PtTri* tris, uint32_t tr
 			float sx = pt_as_float((w0.w & 0xffu) << 23), sy = pt_as_float(((w0.w >> 8) & 0xffu) << 23), sz = pt_as_float(((w0.w >> 16) & 0xffu) << 23);
 			uint32_t imask = w0.w >> 24;
 			float ax = idx * sx, ay = idy * sy, az = idz * sz;
-			float bx = (pt_as_float(w0.x) - origin.x) * idx, by = (pt_as_float(w0.y) - origin.y) * idy, bz = (pt_as_float(w0.z) - origin.z) * idz;
+			float dx = pt_as_float(w0.x) - origin.x, dy = pt_as_float(w0.y) - origin.y, dz = pt_as_float(w0.z) - origin.z;
+			float bx = dx * idx, by = dy * idy, bz = dz * idz;
+			// Slack for the rounding of this test and of the triangle test (see pt_box_test_slack())
+			float slack = pt_box_test_slack(dx, dy, dz, sx, sy, sz);
+			float ex = slack * fabsf(idx), ey = slack * fabsf(idy), ez = slack * fabsf(idz);
+			float bxn = bx - ex, byn = by - ey, bzn = bz - ez, bxf = bx + ex, byf = by + ey, bzf = bz + ez;
 			uint32_t qlox[2] = { w2.x, w2.y }, qloy[2] = { w2.z, w2.w }, qloz[2] = { w3.x, w3.y };
 			uint32_t qhix[2] = { w3.z, w3.w }, qhiy[2] = { w4.x, w4.y }, qhiz[2] = { w4.z, w4.w };
 			uint32_t leafmask = w1.z & 0xffu;
@@ -126,9 +147,9 @@ PT_FN PtHit pt_trace_closest(const PtNode* nodes, const PtTri* tris, uint32_t tr
 				float lx = pt_byte_to_float(qlox[i >> 2], i & 3), hx = pt_byte_to_float(qhix[i >> 2], i & 3);
 				float ly = pt_byte_to_float(qloy[i >> 2], i & 3), hy = pt_byte_to_float(qhiy[i >> 2], i & 3);
 				float lz = pt_byte_to_float(qloz[i >> 2], i & 3), hz = pt_byte_to_float(qhiz[i >> 2], i & 3);
-				float nx = fmaf(neg_x ? hx : lx, ax, bx), fx = fmaf(neg_x ? lx : hx, ax, bx);
-				float ny = fmaf(neg_y ? hy : ly, ay, by), fy = fmaf(neg_y ? ly : hy, ay, by);
-				float nz = fmaf(neg_z ? hz : lz, az, bz), fz = fmaf(neg_z ? lz : hz, az, bz);
+				float nx = fmaf(neg_x ? hx : lx, ax, bxn), fx = fmaf(neg_x ? lx : hx, ax, bxf);
+				float ny = fmaf(neg_y ? hy : ly, ay, byn), fy = fmaf(neg_y ? ly : hy, ay, byf);
+				float nz = fmaf(neg_z ? hz : lz, az, bzn), fz = fmaf(neg_z ? lz : hz, az, bzf);
 				float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
 				float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
 				if (tn <= tf)

@@ -301,7 +301,12 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				float sx = pt_as_float((w0.w & 0xffu) << 23), sy = pt_as_float(((w0.w >> 8) & 0xffu) << 23), sz = pt_as_float(((w0.w >> 16) & 0xffu) << 23);
 				uint32_t imask = w0.w >> 24;
 				float ax = idx * sx, ay = idy * sy, az = idz * sz;
-				float bx = (pt_as_float(w0.x) - origin.x) * idx, by = (pt_as_float(w0.y) - origin.y) * idy, bz = (pt_as_float(w0.z) - origin.z) * idz;
+				float dx = pt_as_float(w0.x) - origin.x, dy = pt_as_float(w0.y) - origin.y, dz = pt_as_float(w0.z) - origin.z;
+				float bx = dx * idx, by = dy * idy, bz = dz * idz;
+				// Near planes a little nearer, far planes a little farther (pt_box_test_slack())
+				float slack = pt_box_test_slack(dx, dy, dz, sx, sy, sz);
+				float ex = slack * fabsf(idx), ey = slack * fabsf(idy), ez = slack * fabsf(idz);
+				float bxn = bx - ex, byn = by - ey, bzn = bz - ez, bxf = bx + ex, byf = by + ey, bzf = bz + ez;
 				// Near and far planes per axis, chosen once per node by the ray's signs
 				uint32_t nqx[2] = { neg_x ? w3.z : w2.x, neg_x ? w3.w : w2.y }, fqx[2] = { neg_x ? w2.x : w3.z, neg_x ? w2.y : w3.w };
 				uint32_t nqy[2] = { neg_y ? w4.x : w2.z, neg_y ? w4.y : w2.w }, fqy[2] = { neg_y ? w2.z : w4.x, neg_y ? w2.w : w4.y };
@@ -312,9 +317,9 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				uint32_t hit8 = 0;
 #pragma unroll
 				for (int i = 0; i != 8; ++i) {
-					float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bx), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bx);
-					float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, by), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, by);
-					float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bz), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bz);
+					float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bxn), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bxf);
+					float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, byn), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, byf);
+					float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bzn), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bzf);
 					float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
 					float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
 					hit8 |= (tn <= tf) ? (1u << i) : 0u;

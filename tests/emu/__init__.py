@@ -41,6 +41,7 @@ def lib():
         _lib.emu_bvh_info.argtypes = [C.c_void_p, C.c_void_p]
         _lib.emu_binary_tree_cost.restype = C.c_double
         _lib.emu_binary_tree_cost.argtypes = [C.c_void_p]
+        _lib.emu_trace_rays_brute_force.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.emu_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.emu_primary_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.emu_render.restype = C.c_uint64
@@ -112,6 +113,15 @@ class EmuScene:
         visits = np.zeros(2, np.uint64)
         lib().emu_trace_rays(self.handle, _ptr(o), _ptr(d), len(o), _ptr(tri), _ptr(tuv), _ptr(front), _ptr(visits))
         return tri, tuv, front, visits
+
+    def trace_rays_brute_force(self, origins, directions):
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, np.float32).reshape(-1, 3)
+        tri = np.zeros(len(o), np.int32)
+        tuv = np.zeros((len(o), 3), np.float32)
+        front = np.zeros(len(o), np.uint8)
+        lib().emu_trace_rays_brute_force(self.handle, _ptr(o), _ptr(d), len(o), _ptr(tri), _ptr(tuv), _ptr(front))
+        return tri, tuv, front
 
     def primary_cones(self, constants, frame_index):
         width, height = int(constants.viewport_size[0]), int(constants.viewport_size[1])

@@ -331,6 +331,23 @@ void emu_trace_rays(EmuScene* s, const float* origins, const float* directions, 
 	if (visits_out) { visits_out[0] = total[0]; visits_out[1] = total[1]; }
 }
 
+// The closest hit by a loop over all triangles with the traversal's own triangle test: what any BVH must return
+void emu_trace_rays_brute_force(EmuScene* s, const float* origins, const float* directions, uint32_t count, int32_t* triangles, float* tuv, uint8_t* front) {
+	for (uint32_t i = 0; i != count; ++i) {
+		v3 origin = mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), dir = mk3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]);
+		PtRayShear shear = pt_ray_shear(dir);
+		PtHit hit;
+		hit.prim = 0xffffffffu; hit.t = 1e38f; hit.u = hit.v = 0.0f; hit.front = false;
+		for (uint32_t j = 0; j != s->n; ++j) {
+			const PtTri& t = s->tris[j];
+			pt_intersect_triangle(hit, shear, origin, mk3(t.v0[0], t.v0[1], t.v0[2]), mk3(t.v1[0], t.v1[1], t.v1[2]), mk3(t.v2[0], t.v2[1], t.v2[2]), t.prim, 1.0e-3f);
+		}
+		triangles[i] = (int32_t) hit.prim;
+		tuv[3 * i] = hit.t; tuv[3 * i + 1] = hit.u; tuv[3 * i + 2] = hit.v;
+		front[i] = hit.front;
+	}
+}
+
 void emu_primary_hits(EmuScene* s, const PtConstants* c, uint32_t frame_index, int32_t* triangles, float* barys, uint8_t* front) {
 	uint32_t w = (uint32_t) c->viewport_size[0], h = (uint32_t) c->viewport_size[1];
 	for (uint32_t y = 0; y != h; ++y) for (uint32_t x = 0; x != w; ++x) {

@@ -80,6 +80,21 @@ def test_traversal_exact(gpu_cornell, oracle_cornell, soup):
         assert (a[0] >= 0).mean() > 0.3
 
 
+@pytest.mark.parametrize("distance", [1.0, 100.0, 10000.0])
+def test_traversal_exact_for_rays_from_far_away(distance):
+    """Rays that start up to 10 000 scene extents away (the CPU suite checks the same rays against a loop over all
+    triangles): the persistent traversal kernel agrees with the oracle's binary BVH bit for bit."""
+    from tests.test_kernel_bodies_cpu import axis_aligned_terraces, far_rays
+    scene = axis_aligned_terraces()
+    g_scene = gpu_scene(scene, np.zeros((0, 4), np.float32))
+    origins, directions = far_rays(np.random.default_rng(int(distance)), 60000, distance)
+    a = oracle.OracleScene(scene).trace_rays(origins, directions)
+    b = g_scene.trace_rays(origins, directions)
+    g_scene.close()
+    assert (a[0] == b[0]).all() and (bits(a[1]) == bits(b[1])).all() and (a[2] == b[2]).all()
+    assert (a[0] >= 0).mean() > 0.6
+
+
 def test_primary_hits_exact_512(gpu_cornell, oracle_cornell, cornell, cornell_lights, cornell_spec):
     """BASELINE config 1 geometry: 512x512 primary rays of frame 2696, triangle IDs bit-exact (no ties to document)."""
     constants = oracle.write_constants(cornell_spec, 512, 512, cornell, cornell_lights)

@@ -234,3 +234,50 @@ def test_light_tree_converges_to_the_loop_over_all_lights():
     print("relative differences of image means", relative, "relative RMSE", rmse)
     assert relative["tree"] < 0.015 and relative["loop again"] < 0.015 and relative["brdf"] < 0.05
     assert rmse["tree"] < 2.0 * rmse["loop again"] + 0.02
+
+
+def axis_aligned_terraces(cells=24):
+    """Axis-aligned squares at two heights with walls between them: boxes without thickness, many of them on the
+    boundaries of BVH nodes, where a box test that is too tight loses hits."""
+    rng = np.random.default_rng(1)
+    tris = []
+    for i in range(cells):
+        for j in range(cells):
+            x0, y0, step = i / cells, j / cells, 1.0 / cells
+            z = 0.0 if (i + j) % 2 == 0 else 0.5
+            a, b, c, d = (x0, y0, z), (x0 + step, y0, z), (x0 + step, y0 + step, z), (x0, y0 + step, z)
+            tris += [[a, b, c], [a, c, d], [(x0, y0, 0.0), (x0, y0 + step, 0.0), (x0, y0 + step, 0.5)]]
+    verts = np.array(tris, np.float64)
+    positions, factor, summand = synthetic.quantize_positions(verts.reshape(-1, 3))
+    count = len(tris)
+    normals_uvs = np.zeros((3 * count, 4), np.uint16)
+    normals_uvs[:, :2] = 32768
+    textures = [synthetic.random_texture(rng, 4, 132), synthetic.random_texture(rng, 4, 131), synthetic.random_texture(rng, 4, 141)]
+    return oracle.formats.Scene(["m"], count, factor, summand, positions, normals_uvs, np.zeros(count, np.uint8), textures)
+
+
+def far_rays(rng, count, distance, cells=24):
+    """Rays towards points of the terraces (half of them on cell edges, a third along the axes) from `distance` away."""
+    targets = rng.uniform(0, 1, (count, 3))
+    targets[:, 2] = rng.choice([0.0, 0.5, 0.25], count)
+    targets[::2, 0] = np.round(targets[::2, 0] * cells) / cells
+    directions = rng.normal(size=(count, 3))
+    directions[::3] = np.round(directions[::3] / np.abs(directions[::3]).max(axis=1, keepdims=True))
+    directions /= np.linalg.norm(directions, axis=1, keepdims=True)
+    origins = targets - directions * distance * rng.uniform(0.5, 2.0, (count, 1))
+    return origins.astype(np.float32), directions.astype(np.float32)
+
+
+@pytest.mark.parametrize("distance", [1.0, 100.0, 10000.0])
+def test_traversal_against_a_loop_over_all_triangles(distance):
+    """The closest hit must not depend on the BVH: traversal of the 8-wide BVH (kernel body) and of the oracle's
+    binary BVH against a loop over all triangles with the same triangle test, for rays that start up to 10 000
+    scene extents away. There the rounding of 'box minus ray origin' exceeds any padding fixed at build time; the
+    box tests give way in proportion to the distance instead."""
+    scene = axis_aligned_terraces()
+    e_scene, o_scene = emu.EmuScene(scene), oracle.OracleScene(scene)
+    origins, directions = far_rays(np.random.default_rng(int(distance)), 15000, distance)
+    expected = e_scene.trace_rays_brute_force(origins, directions)
+    assert (expected[0] >= 0).mean() > 0.6
+    for got in (e_scene.trace_rays(origins, directions), o_scene.trace_rays(origins, directions)):
+        assert (got[0] == expected[0]).all() and (bits(got[1]) == bits(expected[1])).all() and (got[2] == expected[2]).all()

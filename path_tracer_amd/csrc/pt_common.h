@@ -221,7 +221,7 @@ struct PtSceneView {
 	const PtShadeTri* shade_tris; // mesh data as stored in the .vks file, regrouped per triangle
 	const uint8_t* materials;   // 1 per triangle
 	const u32x2* texture_table; // 3 per material, see pt_pack_texture()
-	const uint8_t* texture_blob; // decoded texels of all textures, see pt_fetch_texel()
+	const uint8_t* texture_blob; // decoded texels of all textures, see pt_load_texel()
 	const float* srgb_to_linear; // 256 entries
 	const f32x4* lights;
 	uint32_t light_count;

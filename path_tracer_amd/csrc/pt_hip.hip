@@ -54,6 +54,9 @@ static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device con
 #define PT_SHADE_BLOCK 256
 #endif
 static_assert(sizeof(float) * PT_LIGHT_CACHE_SIZE * PT_SHADE_BLOCK <= 64 * 1024, "dynamic LDS beyond 64 KB has to be requested with hipFuncSetAttribute()");
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 5 // waves per SIMD that the shading kernel is compiled for
+#endif
 #define PT_INVALID 0xffffffffu
 
 #define PT_CHECK(call) do { hipError_t pt_err_ = (call); if (pt_err_ != hipSuccess) { \
@@ -274,6 +277,37 @@ __device__ __forceinline__ void pt_block_push_2(uint32_t* counter_a, bool want_a
 	*out_slot_b = bases[1] + wave_offsets[1][wave] + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask_b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask_b, 0u));
 }
 
+// Sorts the threads of a workgroup into three groups by a class per thread
+// (0, 1, or anything else for "none"): returns the position of this thread
+// among the threads of class 0 followed by those of class 1, each in thread
+// order, and the sizes of both groups. All threads of the workgroup must call
+// this.
+template <uint32_t BLOCK>
+__device__ __forceinline__ uint32_t pt_block_partition(uint32_t cls, uint32_t* out_count_0, uint32_t* out_count_1) {
+	__shared__ uint32_t wave_counts[2][BLOCK / 64];
+	const uint32_t wave = threadIdx.x >> 6;
+	unsigned long long mask_0 = __ballot(cls == 0u), mask_1 = __ballot(cls == 1u);
+	if ((threadIdx.x & 63) == 0) {
+		wave_counts[0][wave] = (uint32_t) __popcll(mask_0);
+		wave_counts[1][wave] = (uint32_t) __popcll(mask_1);
+	}
+	__syncthreads();
+	uint32_t before_0 = 0, before_1 = 0, total_0 = 0, total_1 = 0;
+#pragma unroll
+	for (uint32_t w = 0; w != BLOCK / 64; ++w) {
+		uint32_t c0 = wave_counts[0][w], c1 = wave_counts[1][w];
+		before_0 += (w < wave) ? c0 : 0u;
+		before_1 += (w < wave) ? c1 : 0u;
+		total_0 += c0;
+		total_1 += c1;
+	}
+	*out_count_0 = total_0;
+	*out_count_1 = total_1;
+	uint32_t rank_0 = before_0 + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask_0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask_0, 0u));
+	uint32_t rank_1 = total_0 + before_1 + __builtin_amdgcn_mbcnt_hi((uint32_t) (mask_1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask_1, 0u));
+	return (cls == 0u) ? rank_0 : rank_1;
+}
+
 struct PtTraceArgs {
 	PtSceneView scene;
 	PtWavefront wf;
@@ -373,7 +407,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 		});
 }
 
-// Decodes one mip level (2^log_w texels wide) of a BC1 / BC5 texture into tiled 8-bit texels (pt_fetch_texel() reads them)
+// Decodes one mip level (2^log_w texels wide) of a BC1 / BC5 texture into tiled 8-bit texels (pt_load_texel() reads them)
 __global__ void __launch_bounds__(PT_BLOCK) k_decode_texture(const uint8_t* bc_mip, uint32_t* texels, uint32_t log_w, uint32_t format, uint32_t texel_count) {
 	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
 	if (i >= texel_count)
@@ -404,6 +438,13 @@ __device__ __forceinline__ void pt_stage_srgb_table(const float* table) {
 	__syncthreads();
 }
 
+// Copies the first lights into LDS for pt_light(); all threads of the
+// workgroup take part (pt_stage_srgb_table() after it synchronises them)
+__device__ __forceinline__ void pt_stage_lights(const f32x4* lights, uint32_t light_count) {
+	for (uint32_t i = threadIdx.x; i < light_count && i < PT_LDS_LIGHTS; i += blockDim.x)
+		pt_lights_lds[i] = lights[i];
+}
+
 struct PtShadeArgs {
 	PtSceneView scene;
 	PtWavefront wf;
@@ -423,11 +464,13 @@ extern __shared__ float pt_shade_light_importances[];
 // One instantiation per sampling strategy: the strategy is a compile-time
 // constant inside, so each kernel carries the registers of one estimator only
 template <int STRATEGY>
-__global__ void __launch_bounds__(PT_SHADE_BLOCK, 5) k_shade(PtShadeArgs a) {
+__global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(PtShadeArgs a) {
 	uint32_t first_slot;
 	uint32_t count = a.wf.ext_count[a.k - 1];
 	if (!pt_block_first_slot(count, &first_slot, PT_SHADE_BLOCK))
 		return;
+	if (STRATEGY == PT_STRATEGY_NEE)
+		pt_stage_lights(a.scene.lights, a.scene.light_count);
 	pt_stage_srgb_table(a.scene.srgb_to_linear);
 	// Per-light importances of this thread's vertex between the two loops of
 	// pt_sample_lights(): lane-contiguous, hence free of bank conflicts
@@ -442,12 +485,34 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, 5) k_shade(PtShadeArgs a) {
 	r.continues = false;
 	r.shadow = false;
 	u32x4 hit;
+	hit.x = hit.y = hit.z = 0u;
+	hit.w = PT_INVALID;
 	if (active) {
 		hit = a.wf.hit[slot];
-		path = hit.w;
-		active = path != PT_INVALID;
+		active = hit.w != PT_INVALID;
+	}
+	// Rays that left the scene need a few instructions, hits need thousands:
+	// a wave in which both occur keeps the lanes of the former idle for as long
+	// as the latter take. The workgroup therefore deals its slots out anew,
+	// hits to its first threads and misses to the following ones, so that all
+	// but one of its waves are of one kind. Which thread shades which slot does
+	// not change what a path computes.
+	{
+		__shared__ uint32_t dealt_slots[PT_SHADE_BLOCK];
+		uint32_t hit_count, miss_count;
+		uint32_t cls = !active ? 2u : ((hit.x == PT_INVALID) ? 1u : 0u);
+		uint32_t position = pt_block_partition<PT_SHADE_BLOCK>(cls, &hit_count, &miss_count);
+		if (active)
+			dealt_slots[position] = slot;
+		__syncthreads();
+		active = threadIdx.x < hit_count + miss_count;
+		if (active) {
+			slot = dealt_slots[threadIdx.x];
+			hit = a.wf.hit[slot];
+		}
 	}
 	if (active) {
+		path = hit.w;
 		// The direction carries the ray's cone in its fourth word; the origin is
 		// needed for the distance that the cone has travelled
 		f32x4 d = a.wf.ray_d[a.parity][slot], o = a.wf.ray_o[a.parity][slot];
@@ -1131,7 +1196,7 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 		if (hipMemcpyAsync(s->srgb_to_linear, table, sizeof(table), hipMemcpyHostToDevice, s->stream) != hipSuccess)
 			break;
 		// The texels of all mip levels of all textures decoded into one blob
-		// (pt_fetch_texel()): the block-compressed payloads go to the GPU as they
+		// (pt_load_texel()): the block-compressed payloads go to the GPU as they
 		// are, a kernel decodes them
 		std::vector<PtTexture> descs(texture_count ? texture_count : 1);
 		std::vector<uint64_t> bc_offsets;

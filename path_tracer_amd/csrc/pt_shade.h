@@ -242,28 +242,52 @@ PT_FN float pt_srgb_to_linear(const PtSceneView& s, uint32_t value) {
 #endif
 }
 
-PT_FN v3 pt_fetch_texel(const PtSceneView& s, u32x2 t, uint32_t level, int32_t x, int32_t y) {
-	uint32_t log_w = (t.y & 0xffu) - level, log_h = ((t.y >> 8) & 0xffu) - level, format = (t.y >> 16) & 0xffu;
+// The 8-bit texel (R, G << 8, B << 16) at (x, y) of one mip level, REPEAT addressing
+PT_FN uint32_t pt_load_texel(const PtSceneView& s, u32x2 t, uint32_t level, int32_t x, int32_t y) {
+	uint32_t log_w = (t.y & 0xffu) - level, log_h = ((t.y >> 8) & 0xffu) - level;
 	uint32_t ux = (uint32_t) x & ((1u << log_w) - 1u), uy = (uint32_t) y & ((1u << log_h) - 1u);
 	const uint32_t* texels = (const uint32_t*) (s.texture_blob + ((uint64_t) t.x << 4)) + pt_mip_texel_offset(t.y & 0xffu, (t.y >> 8) & 0xffu, level);
-	uint32_t texel = texels[pt_texel_index(log_w, ux, uy)];
+	return texels[pt_texel_index(log_w, ux, uy)];
+}
+
+// The value of a texel: sRGB decoding for VK_FORMAT_BC1_RGB_SRGB_BLOCK, else unorm
+PT_FN v3 pt_texel_value(const PtSceneView& s, uint32_t format, uint32_t texel) {
 	uint32_t r = texel & 0xffu, g = (texel >> 8) & 0xffu, b = (texel >> 16) & 0xffu;
 	if (format == 132)
 		return mk3(pt_srgb_to_linear(s, r), pt_srgb_to_linear(s, g), pt_srgb_to_linear(s, b));
 	return mk3(pt_unorm8(r), pt_unorm8(g), pt_unorm8(b));
 }
 
-// Bilinear filtering of one mip level with REPEAT addressing
-PT_FN v3 pt_sample_texture_level(const PtSceneView& s, u32x2 t, uint32_t level, v2 uv) {
+// The four texels around a sample position and its weights. Loading them
+// is kept apart from using them: a shaded vertex needs up to 24 texels, and
+// the loads only overlap if nothing that waits for one of them (the sRGB
+// table lookups, the branch on the format) stands between them.
+struct PtTexelQuad {
+	uint32_t t00, t10, t01, t11;
+	float wx, wy;
+};
+
+PT_FN PtTexelQuad pt_load_texel_quad(const PtSceneView& s, u32x2 t, uint32_t level, v2 uv) {
 	float x = uv.x * (float) (1u << ((t.y & 0xffu) - level)) - 0.5f, y = uv.y * (float) (1u << (((t.y >> 8) & 0xffu) - level)) - 0.5f;
 	float fx0 = floorf(x), fy0 = floorf(y);
-	float wx = x - fx0, wy = y - fy0;
 	int32_t x0 = (int32_t) fx0, y0 = (int32_t) fy0;
-	v3 t00 = pt_fetch_texel(s, t, level, x0, y0), t10 = pt_fetch_texel(s, t, level, x0 + 1, y0);
-	v3 t01 = pt_fetch_texel(s, t, level, x0, y0 + 1), t11 = pt_fetch_texel(s, t, level, x0 + 1, y0 + 1);
-	v3 top = t00 * (1.0f - wx) + t10 * wx;
-	v3 bottom = t01 * (1.0f - wx) + t11 * wx;
-	return top * (1.0f - wy) + bottom * wy;
+	PtTexelQuad q;
+	q.wx = x - fx0;
+	q.wy = y - fy0;
+	q.t00 = pt_load_texel(s, t, level, x0, y0);
+	q.t10 = pt_load_texel(s, t, level, x0 + 1, y0);
+	q.t01 = pt_load_texel(s, t, level, x0, y0 + 1);
+	q.t11 = pt_load_texel(s, t, level, x0 + 1, y0 + 1);
+	return q;
+}
+
+// Bilinear filtering of one mip level
+PT_FN v3 pt_filter_texel_quad(const PtSceneView& s, uint32_t format, const PtTexelQuad& q) {
+	v3 t00 = pt_texel_value(s, format, q.t00), t10 = pt_texel_value(s, format, q.t10);
+	v3 t01 = pt_texel_value(s, format, q.t01), t11 = pt_texel_value(s, format, q.t11);
+	v3 top = t00 * (1.0f - q.wx) + t10 * q.wx;
+	v3 bottom = t01 * (1.0f - q.wx) + t11 * q.wx;
+	return top * (1.0f - q.wy) + bottom * q.wy;
 }
 
 // The level of detail of a texture lookup, up to the size of the texture.
@@ -290,21 +314,45 @@ PT_FN float pt_texture_lod_base(float uv_area_2, float world_area_2, float footp
 }
 
 // Trilinear filtering: the two mip levels around lod_base + (log_w + log_h) / 2,
-// clamped to the levels that the texture has
-PT_FN v3 pt_sample_texture(const PtSceneView& s, uint32_t texture_index, v2 uv, float lod_base) {
+// clamped to the levels that the texture has. pt_begin_texture_lookup() issues
+// the loads of both levels, pt_finish_texture_lookup() filters.
+struct PtTextureLookup {
+	uint32_t format;
+	float weight; // of the coarser level
+	PtTexelQuad fine, coarse;
+};
+
+PT_FN PtTextureLookup pt_begin_texture_lookup(const PtSceneView& s, uint32_t texture_index, v2 uv, float lod_base) {
 	u32x2 t = s.texture_table[texture_index];
 	uint32_t last_level = (t.y >> 24) - 1u;
 	float lod = lod_base + 0.5f * (float) ((t.y & 0xffu) + ((t.y >> 8) & 0xffu));
 	lod = fminf(fmaxf(lod, 0.0f), (float) last_level);
 	float floor_lod = floorf(lod);
 	uint32_t level = (uint32_t) floor_lod;
-	float weight = lod - floor_lod;
-	v3 fine = pt_sample_texture_level(s, t, level, uv);
+	PtTextureLookup lookup;
+	lookup.format = (t.y >> 16) & 0xffu;
+	lookup.weight = lod - floor_lod;
+	lookup.fine = pt_load_texel_quad(s, t, level, uv);
+	// Under magnification and at the last level the coarser level has no weight and is not read
+	if (lookup.weight > 0.0f)
+		lookup.coarse = pt_load_texel_quad(s, t, level + 1u, uv);
+	else
+		lookup.coarse = lookup.fine;
+	return lookup;
+}
+
+PT_FN v3 pt_finish_texture_lookup(const PtSceneView& s, const PtTextureLookup& lookup) {
+	v3 fine = pt_filter_texel_quad(s, lookup.format, lookup.fine);
 	// At full weight the coarser level adds nothing (magnification and the last level end here)
-	if (!(weight > 0.0f))
+	if (!(lookup.weight > 0.0f))
 		return fine;
-	v3 coarse = pt_sample_texture_level(s, t, level + 1u, uv);
-	return fine * (1.0f - weight) + coarse * weight;
+	v3 coarse = pt_filter_texel_quad(s, lookup.format, lookup.coarse);
+	return fine * (1.0f - lookup.weight) + coarse * lookup.weight;
+}
+
+PT_FN v3 pt_sample_texture(const PtSceneView& s, uint32_t texture_index, v2 uv, float lod_base) {
+	PtTextureLookup lookup = pt_begin_texture_lookup(s, texture_index, uv, lod_base);
+	return pt_finish_texture_lookup(s, lookup);
 }
 
 
@@ -375,9 +423,13 @@ PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants&
 	v3 face = cross(poss[1] - poss[0], poss[2] - poss[0]);
 	s.footprint = fmaf(cone_spread, pt_length(s.pos - cone_origin), cone_width);
 	float lod_base = pt_texture_lod_base(fabsf(e1.x * e2.y - e2.x * e1.y), pt_length(face), s.footprint, fabsf(dot(normal_geo, out_dir)));
-	v3 base_color = pt_sample_texture(scene, 3 * material + 0, tc, lod_base);
-	v3 specular = pt_sample_texture(scene, 3 * material + 1, tc, lod_base);
-	v3 normal_tex = pt_sample_texture(scene, 3 * material + 2, tc, lod_base);
+	// All texels of the three lookups are requested before the first is used
+	PtTextureLookup base_color_lookup = pt_begin_texture_lookup(scene, 3 * material + 0, tc, lod_base);
+	PtTextureLookup specular_lookup = pt_begin_texture_lookup(scene, 3 * material + 1, tc, lod_base);
+	PtTextureLookup normal_lookup = pt_begin_texture_lookup(scene, 3 * material + 2, tc, lod_base);
+	v3 base_color = pt_finish_texture_lookup(scene, base_color_lookup);
+	v3 specular = pt_finish_texture_lookup(scene, specular_lookup);
+	v3 normal_tex = pt_finish_texture_lookup(scene, normal_lookup);
 	v3 normal_local;
 	normal_local.x = normal_tex.x * 2.0f - 1.0f;
 	normal_local.y = normal_tex.y * 2.0f - 1.0f;
@@ -515,6 +567,31 @@ PT_FN float pt_frostbite_brdf_density(const PtShadingData& s, v3 sampled_dir) {
 }
 
 
+// The lights as the loops over all lights read them. Every thread reads the
+// same light in the same iteration; from HBM that is a load whose latency
+// each of the three loops pays once per light, so the kernels keep a copy of
+// the first PT_LDS_LIGHTS lights in LDS (pt_stage_lights() at their start).
+#define PT_LDS_LIGHTS 64
+// The loops over all lights are chains of dependent operations per light
+// (two divisions and a square root in the first); unrolled, neighbouring
+// lights overlap
+#ifndef PT_LIGHT_UNROLL
+#define PT_LIGHT_UNROLL 1
+#endif
+#define PT_STRINGIFY_2(x) #x
+#define PT_STRINGIFY(x) PT_STRINGIFY_2(x)
+#define PT_LIGHT_LOOP_UNROLL _Pragma(PT_STRINGIFY(unroll PT_LIGHT_UNROLL))
+#if defined(__HIPCC__)
+__shared__ f32x4 pt_lights_lds[PT_LDS_LIGHTS];
+#endif
+PT_FN f32x4 pt_light(const PtSceneView& s, uint32_t index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	if (index < PT_LDS_LIGHTS)
+		return pt_lights_lds[index];
+#endif
+	return s.lights[index];
+}
+
 // ---- pathtrace.frag.glsl:69-83 ----
 PT_FN float pt_spherical_light_importance(f32x4 light, v3 shading_pos, v3 normal) {
 	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
@@ -548,8 +625,9 @@ struct PtLightCache {
 // ---- pathtrace.frag.glsl:120-143 ----
 PT_FN v3 pt_sample_lights(const PtSceneView& scene, const PtLightCache& cache, float* out_total_importance, v3 shading_pos, v3 normal, v2 randoms) {
 	float total = 0.0f;
+	PT_LIGHT_LOOP_UNROLL
 	for (uint32_t i = 0; i != scene.light_count; ++i) {
-		float importance = pt_spherical_light_importance(scene.lights[i], shading_pos, normal);
+		float importance = pt_spherical_light_importance(pt_light(scene, i), shading_pos, normal);
 		if (i < cache.capacity)
 			cache.values[i * cache.stride] = importance;
 		total += importance;
@@ -558,7 +636,7 @@ PT_FN v3 pt_sample_lights(const PtSceneView& scene, const PtLightCache& cache, f
 	float target_importance = randoms.x * total;
 	float prefix_importance = 0.0f;
 	for (uint32_t i = 0; i != scene.light_count; ++i) {
-		f32x4 light = scene.lights[i];
+		f32x4 light = pt_light(scene, i);
 		float importance = (i < cache.capacity) ? cache.values[i * cache.stride] : pt_spherical_light_importance(light, shading_pos, normal);
 		prefix_importance += importance;
 		if (prefix_importance > target_importance) {
@@ -577,8 +655,9 @@ PT_FN void pt_lights_density_2(const PtSceneView& scene, float total_importance,
 	if (total_importance <= 0.0f)
 		return;
 	float count_0 = 0.0f, count_1 = 0.0f;
+	PT_LIGHT_LOOP_UNROLL
 	for (uint32_t i = 0; i != scene.light_count; ++i) {
-		f32x4 light = scene.lights[i];
+		f32x4 light = pt_light(scene, i);
 		v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
 		float center_dist_2 = dot(center_dir, center_dir);
 		float radius_2 = light.w * light.w;

@@ -1,9 +1,10 @@
 #!/bin/bash
 # Copies the profiling results of scripts/gpu_profile.sh and scripts/gpu_pmc.sh runs tagged cornell_<tag> and city_<tag>
-# from gpurun_out/ into profiles/r1/<tag>/ and rebuilds profiles/pmc_current.json. usage: scripts/collect_profiles.sh <tag>
+# from gpurun_out/ into profiles/<round>/<tag>/ and rebuilds profiles/pmc_current.json. usage: scripts/collect_profiles.sh <tag> [round, default r2]
 set -e
 tag=$1
-dst=profiles/r1/$tag
+round=${2:-r2}
+dst=profiles/$round/$tag
 mkdir -p $dst
 for w in cornell city; do
 	cp gpurun_out/pmc_${w}_$tag/summary.txt $dst/pmc_${w}_summary.txt

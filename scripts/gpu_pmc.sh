@@ -20,5 +20,7 @@ pass fetch "FETCH_SIZE" "$@" || exit 1
 pass write "WRITE_SIZE" "$@" || exit 1
 pass sq "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "$@" || exit 1
 pass tcc "TCC_HIT_sum TCC_MISS_sum" "$@" || exit 1
+# Where the waves spend their time: issuing, waiting for an issue slot, parked on a wait instruction (quad-cycles summed over waves)
+pass sqwait "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "$@" || exit 1
 python3 $GRAFT_REPO_ROOT/scripts/pmc_summary.py $out > $out/summary.txt
 cat $out/summary.txt

@@ -144,8 +144,10 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	uint32_t reserve_next = 0, reserve_end = 0;
 	bool rays_remain = ray_total != 0;
 	const float tmin = 1.0e-3f;
-	// Per-lane ray state
-	bool active = false;
+	// Per-lane ray state. A ray that is complete stays in its lane (unfinished)
+	// until the wave refills or ends: finish() then runs for many lanes at once
+	// instead of in nearly every pass for the one or two rays that just ended
+	bool active = false, unfinished = false;
 	uint32_t slot = 0;
 	float origin_w = 0.0f, direction_w = 0.0f;
 	v3 origin = mk3(0.0f, 0.0f, 0.0f);
@@ -185,6 +187,10 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		if (rays_remain && ((uint32_t) __popcll(idle_mask) >= PT_REFILL_MIN)) {
 			if (COUNT_VISITS)
 				++refill_count;
+			if (unfinished) {
+				finish(slot, origin_w, direction_w, hit);
+				unfinished = false;
+			}
 			if (reserve_next == reserve_end) {
 				// Reserve the next block of rays of this wave's current eighth
 				uint32_t chunk_begin = chunk * chunk_len;
@@ -250,6 +256,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		}
 		// ---- exit: nothing in flight and nothing left to fetch ----
 		if (!rays_remain && __ballot(active) == 0) {
+			if (unfinished)
+				finish(slot, origin_w, direction_w, hit);
 			drained = true;
 			break;
 		}
@@ -369,8 +377,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 
 		// ---- retire complete rays ----
 		if (active && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0) {
-			finish(slot, origin_w, direction_w, hit);
 			active = false;
+			unfinished = true;
 		}
 	}
 	if (!drained && lane == 0)

@@ -278,7 +278,7 @@ def main():
         counters, counter_source = measured_counters(args.workload, "k_trace_%s<false>" % dominant) if profiled else (None, None)
         # What bounds the kernel, from what the hardware counted rather than from the byte model: the HBM traffic
         # of a launch against the 8 TB/s of the part, and the VALU wave instructions of a launch against what the
-        # 1024 SIMDs can issue. The larger fraction names the bound. The byte model of the survey (every node and
+        # 1024 SIMDs can issue. The larger fraction names the bound. The byte model (every node and
         # triangle visit at full size) stays beside it as a diagnostic: most of those bytes come out of LDS and L2,
         # so as a rate it exceeds what HBM could deliver.
         launch_s = d["avg_ms"] * 1e-3

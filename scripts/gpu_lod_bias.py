@@ -1,8 +1,8 @@
 """How far the level-of-detail rule (ray cones, trilinear) moves a converged image: the generated city rendered with
 its mip chains against the same scene whose textures keep level 0 only (every lookup bilinear at full resolution,
 which with the pixel jitter converges to the unfiltered ground truth), and both against a second run with other frame
-indices (the noise floor at that sample count). Prints relative RMSE figures; used for the tolerance
-stated in DESIGN.md. usage: python scripts/gpu_lod_bias.py [spp] [width] [height]"""
+indices (the noise floor at that sample count). Prints relative RMSE figures, from which the
+tolerance against a driver's filter is stated. usage: python scripts/gpu_lod_bias.py [spp] [width] [height]"""
 import glob
 import os
 import shutil

@@ -321,6 +321,7 @@ def main():
             "all_reduce_ms": all_reduce_seconds * 1e3,
             "roofline": roofline,
             "kernel_ms": {name: stats.kernel_ms[i] for i, name in enumerate(hip_api.KERNEL_NAMES)},
+            "traversal": {name: {"nodes_per_ray": k["nodes_per_ray"], "triangles_per_ray": k["tris_per_ray"], "avg_launch_ms": k["avg_ms"]} for name, k in kernels.items()},
             "bvh": {"nodes": info.node_count, "triangles": info.triangle_count, "depth": info.depth, "build_ms": info.build_ms},
         }
         if not args.no_cpu_baseline and world_size == 1:

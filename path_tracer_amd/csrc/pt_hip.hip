@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 				emission = mk3(c.emission_material_radiance[0], c.emission_material_radiance[1], c.emission_material_radiance[2]);
 			else
 				emission = mk3(0.0f, 0.0f, 0.0f);
-			f32x4 w = a.wf.sh_w[slot];
+			f32x4 w = pt_load_streaming(&a.wf.sh_w[slot]);
 			v3 term = (mk3(w.x, w.y, w.z) * emission) * factor;
 			// Adding a zero leaves the radiance as it is (it is never -0), so the
 			// read-modify-write happens only for terms that are not zero; a NaN
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(PtShad
 		path = hit.w;
 		// The direction carries the ray's cone in its fourth word; the origin is
 		// needed for the distance that the cone has travelled
-		f32x4 d = a.wf.ray_d[a.parity][slot], o = a.wf.ray_o[a.parity][slot];
+		f32x4 d = pt_load_streaming(&a.wf.ray_d[a.parity][slot]), o = pt_load_streaming(&a.wf.ray_o[a.parity][slot]);
 		v3 throughput = mk3(1.0f, 1.0f, 1.0f), nee_throughput = mk3(1.0f, 1.0f, 1.0f), emitted = mk3(0.0f, 0.0f, 0.0f);
 		uint32_t sx, sy;
 		if (a.k == 1) {
@@ -552,13 +552,13 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(PtShad
 	uint32_t next_slot, shadow_slot;
 	pt_block_push_2<PT_SHADE_BLOCK>(&a.wf.ext_count[a.k], r.continues, &a.wf.shadow_count[a.k], r.shadow, &next_slot, &shadow_slot);
 	if (r.continues) {
-		a.wf.ray_o[a.parity ^ 1][next_slot] = mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path));
-		a.wf.ray_d[a.parity ^ 1][next_slot] = mk4(r.next_dir.x, r.next_dir.y, r.next_dir.z, r.next_cone);
+		pt_store_streaming(&a.wf.ray_o[a.parity ^ 1][next_slot], mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path)));
+		pt_store_streaming(&a.wf.ray_d[a.parity ^ 1][next_slot], mk4(r.next_dir.x, r.next_dir.y, r.next_dir.z, r.next_cone));
 	}
 	if (r.shadow) {
-		a.wf.sh_o[shadow_slot] = mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path));
-		a.wf.sh_d[shadow_slot] = mk4(r.shadow_dir.x, r.shadow_dir.y, r.shadow_dir.z, r.shadow_factor);
-		a.wf.sh_w[shadow_slot] = mk4(r.shadow_weight.x, r.shadow_weight.y, r.shadow_weight.z, 0.0f);
+		pt_store_streaming(&a.wf.sh_o[shadow_slot], mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path)));
+		pt_store_streaming(&a.wf.sh_d[shadow_slot], mk4(r.shadow_dir.x, r.shadow_dir.y, r.shadow_dir.z, r.shadow_factor));
+		pt_store_streaming(&a.wf.sh_w[shadow_slot], mk4(r.shadow_weight.x, r.shadow_weight.y, r.shadow_weight.z, 0.0f));
 	}
 }
 

@@ -121,6 +121,20 @@ __device__ __forceinline__ u32x4 pt_to_u32x4(pt_vec4 v) { u32x4 r; r.x = v.x; r.
 __device__ __forceinline__ u32x4 pt_load_lds(const u32x4* p) { return pt_to_u32x4(*(const pt_lds_vec4*) p); }
 __device__ __forceinline__ u32x4 pt_load_global(const u32x4* p) { return pt_to_u32x4(*(const pt_global_vec4*) p); }
 
+// Loads and stores of the ray queues, which a launch touches once: marked
+// non-temporal, so that the caches prefer to keep the BVH. (The hit records
+// are not: shading reads them right after the traversal has written them.)
+typedef float pt_float4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 pt_load_streaming(const f32x4* p) {
+	pt_float4 v = __builtin_nontemporal_load((const pt_float4*) p);
+	f32x4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w;
+	return r;
+}
+__device__ __forceinline__ void pt_store_streaming(f32x4* p, f32x4 value) {
+	pt_float4 v = { value.x, value.y, value.z, value.w };
+	__builtin_nontemporal_store(v, (pt_float4*) p);
+}
+
 __device__ __forceinline__ uint32_t pt_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Calls finish(slot, origin_w, direction_w, hit) once per ray of the queue
@@ -219,7 +233,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				uint32_t want = (uint32_t) __popcll(idle_mask);
 				if (!active && rank < available) {
 					slot = reserve_next + rank;
-					f32x4 o = queue.origin[slot], d = queue.direction[slot];
+					f32x4 o = pt_load_streaming(&queue.origin[slot]), d = pt_load_streaming(&queue.direction[slot]);
 					origin_w = o.w;
 					direction_w = d.w;
 					active = true;

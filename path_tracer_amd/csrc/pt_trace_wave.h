@@ -180,7 +180,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	u32x2 ngroup, tgroup;
 	ngroup.x = ngroup.y = tgroup.x = tgroup.y = 0;
 	uint32_t sp = 0;
-	uint32_t node_visits = 0, tri_visits = 0;
+	uint32_t node_visits = 0, tri_visits = 0, lds_node_visits = 0, lds_tri_visits = 0;
 	uint32_t pass_count = 0, refill_count = 0, node_pass_count = 0, tri_pass_count = 0;
 	(void) node_pass_count; (void) tri_pass_count;
 	unsigned long long active_lane_passes = 0;
@@ -309,8 +309,10 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				uint32_t child_slot = (bit - 24u) ^ octinv;
 				uint32_t rel = (uint32_t) __builtin_popcount(ngroup.y & 0xffu & ((1u << child_slot) - 1u));
 				uint32_t node_index = ngroup.x + rel;
-				if (COUNT_VISITS)
+				if (COUNT_VISITS) {
 					++node_visits;
+					lds_node_visits += (node_index < layout.node_count) ? 1u : 0u;
+				}
 				u32x4 w0, w1, w2, w3, w4;
 				if (node_index < layout.node_count) {
 					const u32x4* words = &cache[5 * node_index];
@@ -372,8 +374,10 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			uint32_t bit = (uint32_t) __builtin_ctz(tgroup.y);
 			tgroup.y &= tgroup.y - 1u;
 			uint32_t tri_index = tgroup.x + (uint32_t) __builtin_popcount((tgroup.y >> 8) & ((1u << bit) - 1u));
-			if (COUNT_VISITS)
+			if (COUNT_VISITS) {
 				++tri_visits;
+				lds_tri_visits += (tri_index < layout.tri_count) ? 1u : 0u;
+			}
 			u32x4 t0, t1, t2;
 			if (tri_index < layout.tri_count) {
 				const u32x4* words = &cache[layout.tri_offset + 3 * tri_index];
@@ -400,6 +404,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	if (COUNT_VISITS) {
 		atomicAdd(&visit_counters[0], (unsigned long long) node_visits);
 		atomicAdd(&visit_counters[1], (unsigned long long) tri_visits);
+		atomicAdd(&visit_counters[20], (unsigned long long) lds_node_visits);
+		atomicAdd(&visit_counters[21], (unsigned long long) lds_tri_visits);
 		if (lane == 0) {
 			// Diagnostics: passes, lanes active in them, refills (summed over waves)
 			atomicAdd(&visit_counters[6], (unsigned long long) pass_count);

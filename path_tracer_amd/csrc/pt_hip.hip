@@ -438,13 +438,6 @@ __device__ __forceinline__ void pt_stage_srgb_table(const float* table) {
 	__syncthreads();
 }
 
-// Copies the first lights into LDS for pt_light(); all threads of the
-// workgroup take part (pt_stage_srgb_table() after it synchronises them)
-__device__ __forceinline__ void pt_stage_lights(const f32x4* lights, uint32_t light_count) {
-	for (uint32_t i = threadIdx.x; i < light_count && i < PT_LDS_LIGHTS; i += blockDim.x)
-		pt_lights_lds[i] = lights[i];
-}
-
 struct PtShadeArgs {
 	PtSceneView scene;
 	PtWavefront wf;
@@ -469,8 +462,6 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(PtShad
 	uint32_t count = a.wf.ext_count[a.k - 1];
 	if (!pt_block_first_slot(count, &first_slot, PT_SHADE_BLOCK))
 		return;
-	if (STRATEGY == PT_STRATEGY_NEE)
-		pt_stage_lights(a.scene.lights, a.scene.light_count);
 	pt_stage_srgb_table(a.scene.srgb_to_linear);
 	// Per-light importances of this thread's vertex between the two loops of
 	// pt_sample_lights(): lane-contiguous, hence free of bank conflicts

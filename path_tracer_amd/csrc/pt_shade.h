@@ -568,10 +568,10 @@ PT_FN float pt_frostbite_brdf_density(const PtShadingData& s, v3 sampled_dir) {
 
 
 // The lights as the loops over all lights read them. Every thread reads the
-// same light in the same iteration; from HBM that is a load whose latency
-// each of the three loops pays once per light, so the kernels keep a copy of
-// the first PT_LDS_LIGHTS lights in LDS (pt_stage_lights() at their start).
-#define PT_LDS_LIGHTS 64
+// same light in the same iteration, so on the GPU the read goes through the
+// constant address space: a scalar load into registers that the whole wave
+// shares, served by the scalar cache, with no vector memory instruction and no
+// LDS access per light. (The lights do not change while a kernel runs.)
 // The loops over all lights are chains of dependent operations per light
 // (two divisions and a square root in the first); unrolled, neighbouring
 // lights overlap
@@ -581,15 +581,33 @@ PT_FN float pt_frostbite_brdf_density(const PtShadingData& s, v3 sampled_dir) {
 #define PT_STRINGIFY_2(x) #x
 #define PT_STRINGIFY(x) PT_STRINGIFY_2(x)
 #define PT_LIGHT_LOOP_UNROLL _Pragma(PT_STRINGIFY(unroll PT_LIGHT_UNROLL))
-#if defined(__HIPCC__)
-__shared__ f32x4 pt_lights_lds[PT_LDS_LIGHTS];
-#endif
 PT_FN f32x4 pt_light(const PtSceneView& s, uint32_t index) {
 #if defined(__HIP_DEVICE_COMPILE__)
-	if (index < PT_LDS_LIGHTS)
-		return pt_lights_lds[index];
-#endif
+	typedef float pt_light_words __attribute__((ext_vector_type(4)));
+	typedef __attribute__((address_space(4))) const pt_light_words pt_constant_light;
+	pt_light_words words = ((pt_constant_light*) s.lights)[index];
+	return mk4(words.x, words.y, words.z, words.w);
+#else
 	return s.lights[index];
+#endif
+}
+
+// sqrtf(x) for an x that is zero or not below 2^-96, bit for bit: the
+// hardware's square root (one unit in the last place) corrected by the signs
+// of two exact residuals, which is what the compiler emits for sqrtf() minus
+// the rescaling of smaller arguments (nine more instructions around it). For
+// x = 0 the root is 0, the lower candidate is a NaN and the upper one leaves a
+// residual of zero, so 0 comes out as it is.
+PT_FN float pt_sqrt_at_least_2_pow_minus_96(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+	float root = __builtin_amdgcn_sqrtf(x);
+	float below = pt_as_float(pt_as_uint(root) - 1u), above = pt_as_float(pt_as_uint(root) + 1u);
+	float residual_below = fmaf(-below, root, x), residual_above = fmaf(-above, root, x);
+	root = (residual_below <= 0.0f) ? below : root;
+	return (residual_above > 0.0f) ? above : root;
+#else
+	return sqrtf(x);
+#endif
 }
 
 // ---- pathtrace.frag.glsl:69-83 ----
@@ -599,7 +617,9 @@ PT_FN float pt_spherical_light_importance(f32x4 light, v3 shading_pos, v3 normal
 		return 0.0f;
 	float center_dist_2 = dot(center_dir, center_dir);
 	float sin_2 = light.w * light.w / center_dist_2;
-	return sin_2 / (1.0f + sqrtf(fmaxf(0.0f, 1.0f - sin_2)));
+	// 1 - sin_2 is a multiple of 2^-24 when sin_2 is 1/2 or more and above 1/2
+	// otherwise, so the argument of the root is zero or at least 2^-24
+	return sin_2 / (1.0f + pt_sqrt_at_least_2_pow_minus_96(fmaxf(0.0f, 1.0f - sin_2)));
 }
 
 // ---- pathtrace.frag.glsl:95-106 ----

@@ -304,6 +304,12 @@ def main():
             "valu_lane_utilisation": counters.get("valu_lane_utilisation") if counters else None,
             "valu_instructions_per_launch": counters.get("valu_instructions_per_launch") if counters else None,
             "l2_hit_rate": counters.get("l2_hit_rate") if counters else None,
+            # The vector memory path of the same counter passes: share of the kernel's cycles in which a CU's address
+            # unit has work / is stalled by the vector L1, and what an L1 read request to L2 takes
+            "address_unit_busy_frac": counters.get("address_unit_busy_frac") if counters else None,
+            "address_unit_stalled_by_l1_frac": counters.get("address_unit_stalled_by_l1_frac") if counters else None,
+            "l2_read_latency_cycles": counters.get("l2_read_latency_cycles") if counters else None,
+            "l1_read_requests_per_cycle_and_cu": counters.get("l1_read_requests_per_cycle_and_cu") if counters else None,
             "avg_launch_ms": d["avg_ms"], "rays_per_launch": d["rays_per_launch"],
             "algorithmic_bytes_per_launch": d["bytes_per_ray"] * d["rays_per_launch"], "algorithmic_gbs": d["achieved_gbs"],
             "bytes_per_ray": d["bytes_per_ray"], "nodes_per_ray": d["nodes_per_ray"], "triangles_per_ray": d["tris_per_ray"]})

@@ -28,6 +28,17 @@ for kernel, c in counters.items():
         entry["valu_lane_utilisation"] = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_INSTS_VALU"])
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         entry["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    if "TA_TA_BUSY_sum" in c and "GRBM_GUI_ACTIVE" in c:
+        # One address unit and one vector L1 per CU (256); GRBM_GUI_ACTIVE is the sum over the 8 XCDs
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0
+        entry["kernel_cycles"] = cycles
+        entry["address_unit_busy_frac"] = c["TA_TA_BUSY_sum"] / 256.0 / cycles
+        entry["address_unit_stalled_by_l1_frac"] = c.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum", 0.0) / 256.0 / cycles
+        entry["l1_pending_miss_stall_frac"] = c.get("TCP_PENDING_STALL_CYCLES_sum", 0.0) / 256.0 / cycles
+        if c.get("TCP_TCC_READ_REQ_sum"):
+            entry["l1_read_requests_to_l2_per_launch"] = c["TCP_TCC_READ_REQ_sum"]
+            entry["l2_read_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"]
+            entry["l1_read_requests_per_cycle_and_cu"] = c["TCP_TCC_READ_REQ_sum"] / 256.0 / cycles
     result[kernel] = entry
 existing = json.load(open(target)) if os.path.exists(target) else {}
 existing[workload] = {"source": summary, "kernels": result}

@@ -135,6 +135,72 @@ __device__ __forceinline__ void pt_store_streaming(f32x4* p, f32x4 value) {
 	__builtin_nontemporal_store(v, (pt_float4*) p);
 }
 
+// a where the mask is all ones, b where it is zero. One three-operand bit
+// instruction, which this part executes at the rate of an addition, where a
+// conditional move by a lane mask (and the comparison that makes the mask)
+// takes twice as long each.
+__device__ __forceinline__ uint32_t pt_select_bits(uint32_t mask, uint32_t a, uint32_t b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xca); }
+__device__ __forceinline__ float pt_select_bits(uint32_t mask, float a, float b) { return pt_as_float(pt_select_bits(mask, pt_as_uint(a), pt_as_uint(b))); }
+
+// The ray-dependent part of pt_intersect_triangle() for one lane. Instead of
+// three component indices, which make every vertex component a choice between
+// three registers by two comparisons, the lane keeps masks: two that rotate
+// the dominant axis of the ray into z and one that swaps x and y afterwards
+// (pt_ray_shear() swaps them for a ray that runs against its dominant axis).
+struct PtLaneShear {
+	uint32_t rotate_0, rotate_1; // all ones if the dominant axis is x / y
+	uint32_t swap;               // all ones if kx is the axis after ky
+	float sx, sy, sz;
+};
+
+__device__ __forceinline__ PtLaneShear pt_lane_shear(v3 dir) {
+	PtRayShear r = pt_ray_shear(dir);
+	PtLaneShear l;
+	l.rotate_0 = (r.kz == 0) ? 0xffffffffu : 0u;
+	l.rotate_1 = (r.kz == 1) ? 0xffffffffu : 0u;
+	l.swap = (r.kx != ((r.kz == 2) ? 0 : r.kz + 1)) ? 0xffffffffu : 0u;
+	l.sx = r.sx; l.sy = r.sy; l.sz = r.sz;
+	return l;
+}
+
+// The components kx, ky, kz of v
+__device__ __forceinline__ v3 pt_permute(const PtLaneShear& r, v3 v) {
+	float x = pt_select_bits(r.rotate_0, v.y, pt_select_bits(r.rotate_1, v.z, v.x));
+	float y = pt_select_bits(r.rotate_0, v.z, pt_select_bits(r.rotate_1, v.x, v.y));
+	float z = pt_select_bits(r.rotate_0, v.x, pt_select_bits(r.rotate_1, v.y, v.z));
+	return mk3(pt_select_bits(r.swap, y, x), pt_select_bits(r.swap, x, y), z);
+}
+
+// pt_intersect_triangle() with the lane's masks in place of indices: the same
+// operations on the same values
+__device__ __forceinline__ void pt_intersect_triangle_lane(PtHit& hit, const PtLaneShear& r, v3 origin, v3 p0, v3 p1, v3 p2, uint32_t prim, float tmin) {
+	v3 a = pt_permute(r, p0 - origin), b = pt_permute(r, p1 - origin), c = pt_permute(r, p2 - origin);
+	float az = a.z, bz = b.z, cz = c.z;
+	float ax = a.x - r.sx * az, ay = a.y - r.sy * az;
+	float bx = b.x - r.sx * bz, by = b.y - r.sy * bz;
+	float cx = c.x - r.sx * cz, cy = c.y - r.sy * cz;
+	float u = cx * by - cy * bx;
+	float v = ax * cy - ay * cx;
+	float w = bx * ay - by * ax;
+	if ((u < 0.0f || v < 0.0f || w < 0.0f) && (u > 0.0f || v > 0.0f || w > 0.0f))
+		return;
+	float det = (u + v) + w;
+	if (det == 0.0f)
+		return;
+	float tz = (u * (r.sz * az) + v * (r.sz * bz)) + w * (r.sz * cz);
+	float rcp_det = 1.0f / det;
+	float t = tz * rcp_det;
+	if (!(t > tmin))
+		return;
+	if (t < hit.t || (t == hit.t && prim < hit.prim)) {
+		hit.t = t;
+		hit.prim = prim;
+		hit.u = v * rcp_det;
+		hit.v = w * rcp_det;
+		hit.front = det > 0.0f;
+	}
+}
+
 __device__ __forceinline__ uint32_t pt_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Calls finish(slot, origin_w, direction_w, hit) once per ray of the queue
@@ -166,11 +232,11 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	float origin_w = 0.0f, direction_w = 0.0f;
 	v3 origin = mk3(0.0f, 0.0f, 0.0f);
 	float idx = 0.0f, idy = 0.0f, idz = 0.0f;
-	bool neg_x = false, neg_y = false, neg_z = false;
+	// All ones for a ray that runs against the axis
+	uint32_t neg_x = 0, neg_y = 0, neg_z = 0;
 	uint32_t octinv = 7;
-	uint32_t swap_mask_1 = 0x55, swap_mask_2 = 0x33, swap_mask_4 = 0x0f;
-	PtRayShear shear;
-	shear.kx = 0; shear.ky = 1; shear.kz = 2;
+	PtLaneShear shear;
+	shear.rotate_0 = shear.rotate_1 = shear.swap = 0;
 	shear.sx = shear.sy = shear.sz = 0.0f;
 	PtHit hit;
 	hit.prim = 0xffffffffu;
@@ -249,18 +315,17 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					}
 					else {
 						origin = mk3(o.x, o.y, o.z);
-						shear = pt_ray_shear(mk3(d.x, d.y, d.z));
+						shear = pt_lane_shear(mk3(d.x, d.y, d.z));
 						// The box test may be conservative, so tiny direction
 						// components are clamped to keep reciprocals finite
 						float cdx = (fabsf(d.x) > 1.0e-30f) ? d.x : copysignf(1.0e-30f, d.x);
 						float cdy = (fabsf(d.y) > 1.0e-30f) ? d.y : copysignf(1.0e-30f, d.y);
 						float cdz = (fabsf(d.z) > 1.0e-30f) ? d.z : copysignf(1.0e-30f, d.z);
 						idx = 1.0f / cdx; idy = 1.0f / cdy; idz = 1.0f / cdz;
-						neg_x = cdx < 0.0f; neg_y = cdy < 0.0f; neg_z = cdz < 0.0f;
-						octinv = 7u - ((neg_x ? 1u : 0u) | (neg_y ? 2u : 0u) | (neg_z ? 4u : 0u));
-						swap_mask_1 = neg_x ? 0u : 0x55u;
-						swap_mask_2 = neg_y ? 0u : 0x33u;
-						swap_mask_4 = neg_z ? 0u : 0x0fu;
+						neg_x = (cdx < 0.0f) ? 0xffffffffu : 0u;
+						neg_y = (cdy < 0.0f) ? 0xffffffffu : 0u;
+						neg_z = (cdz < 0.0f) ? 0xffffffffu : 0u;
+						octinv = 7u - ((neg_x & 1u) | (neg_y & 2u) | (neg_z & 4u));
 						ngroup.x = 0;
 						ngroup.y = 0x80000000u;
 					}
@@ -332,30 +397,38 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				float ex = slack * fabsf(idx), ey = slack * fabsf(idy), ez = slack * fabsf(idz);
 				float bxn = bx - ex, byn = by - ey, bzn = bz - ez, bxf = bx + ex, byf = by + ey, bzf = bz + ez;
 				// Near and far planes per axis, chosen once per node by the ray's signs
-				uint32_t nqx[2] = { neg_x ? w3.z : w2.x, neg_x ? w3.w : w2.y }, fqx[2] = { neg_x ? w2.x : w3.z, neg_x ? w2.y : w3.w };
-				uint32_t nqy[2] = { neg_y ? w4.x : w2.z, neg_y ? w4.y : w2.w }, fqy[2] = { neg_y ? w2.z : w4.x, neg_y ? w2.w : w4.y };
-				uint32_t nqz[2] = { neg_z ? w4.z : w3.x, neg_z ? w4.w : w3.y }, fqz[2] = { neg_z ? w3.x : w4.z, neg_z ? w3.y : w4.w };
+				uint32_t nqx[2] = { pt_select_bits(neg_x, w3.z, w2.x), pt_select_bits(neg_x, w3.w, w2.y) }, fqx[2] = { pt_select_bits(neg_x, w2.x, w3.z), pt_select_bits(neg_x, w2.y, w3.w) };
+				uint32_t nqy[2] = { pt_select_bits(neg_y, w4.x, w2.z), pt_select_bits(neg_y, w4.y, w2.w) }, fqy[2] = { pt_select_bits(neg_y, w2.z, w4.x), pt_select_bits(neg_y, w2.w, w4.y) };
+				uint32_t nqz[2] = { pt_select_bits(neg_z, w4.z, w3.x), pt_select_bits(neg_z, w4.w, w3.y) }, fqz[2] = { pt_select_bits(neg_z, w3.x, w4.z), pt_select_bits(neg_z, w3.y, w4.w) };
 				uint32_t leafmask = w1.z & 0xffu;
 				// Eight box tests back to back without branches: bit i of hit8 says
-				// whether child slot i was hit (empty slots are masked out below)
-				uint32_t hit8 = 0;
+				// whether child slot i was hit (empty slots are masked out below).
+				// tn <= tf is read off the sign of tf - tn, shifted into the mask
+				// from the last child to the first: a subtraction and a funnel
+				// shift per child instead of a comparison, a conditional move and
+				// an or. tn and tf are no NaNs (the maxima and minima drop them),
+				// equal values give +0, and should two infinities of one sign make
+				// the difference a NaN, its sign bit is clear: the child counts as
+				// hit, which costs a visit and no more.
+				uint32_t missed8 = 0;
 #pragma unroll
-				for (int i = 0; i != 8; ++i) {
+				for (int i = 7; i >= 0; --i) {
 					float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bxn), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bxf);
 					float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, byn), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, byf);
 					float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bzn), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bzf);
 					float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
 					float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
-					hit8 |= (tn <= tf) ? (1u << i) : 0u;
+					missed8 = __builtin_amdgcn_alignbit(missed8, pt_as_uint(tf - tn), 31);
 				}
+				uint32_t hit8 = ~missed8 & 0xffu;
 				// Inner children: from slot order to visiting order (slot ^ octinv),
 				// three conditional swaps of neighbouring bits, pairs and nibbles
 				uint32_t order = hit8 & imask;
-				uint32_t swap = ((order >> 1) ^ order) & swap_mask_1;
+				uint32_t swap = ((order >> 1) ^ order) & (0x55u & ~neg_x);
 				order ^= swap | (swap << 1);
-				swap = ((order >> 2) ^ order) & swap_mask_2;
+				swap = ((order >> 2) ^ order) & (0x33u & ~neg_y);
 				order ^= swap | (swap << 2);
-				swap = ((order >> 4) ^ order) & swap_mask_4;
+				swap = ((order >> 4) ^ order) & (0x0fu & ~neg_z);
 				order ^= swap | (swap << 4);
 				ngroup.x = w1.x;
 				ngroup.y = (order << 24) | imask;
@@ -387,7 +460,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				const u32x4* words = (const u32x4*) &tris[tri_index];
 				t0 = pt_load_global(words); t1 = pt_load_global(words + 1); t2 = pt_load_global(words + 2);
 			}
-			pt_intersect_triangle(hit, shear, origin,
+			pt_intersect_triangle_lane(hit, shear, origin,
 				mk3(pt_as_float(t0.x), pt_as_float(t0.y), pt_as_float(t0.z)),
 				mk3(pt_as_float(t0.w), pt_as_float(t1.x), pt_as_float(t1.y)),
 				mk3(pt_as_float(t1.z), pt_as_float(t1.w), pt_as_float(t2.x)), t2.y, tmin);

@@ -84,6 +84,27 @@ KERNEL(k_add_co, "v_add_co_u32 %0, vcc, %1, %0")
 KERNEL(k_fma_abs, "v_fma_f32 %0, |%1|, %2, %0")
 KERNEL(k_mul_e64, "v_mul_f32_e64 %0, |%1|, %0")
 
+// Two different instructions in turn (16 of each per 32): do their costs add, or do they run on different pipes?
+#define OP8_MIXED(text_a, text_b) \
+	asm volatile(text_a : "+v"(a0) : "v"(b), "v"(c) : "vcc", "s10", "s11"); asm volatile(text_b : "+v"(a1) : "v"(b), "v"(c) : "vcc", "s10", "s11"); \
+	asm volatile(text_a : "+v"(a2) : "v"(b), "v"(c) : "vcc", "s10", "s11"); asm volatile(text_b : "+v"(a3) : "v"(b), "v"(c) : "vcc", "s10", "s11"); \
+	asm volatile(text_a : "+v"(a4) : "v"(b), "v"(c) : "vcc", "s10", "s11"); asm volatile(text_b : "+v"(a5) : "v"(b), "v"(c) : "vcc", "s10", "s11"); \
+	asm volatile(text_a : "+v"(a6) : "v"(b), "v"(c) : "vcc", "s10", "s11"); asm volatile(text_b : "+v"(a7) : "v"(b), "v"(c) : "vcc", "s10", "s11");
+#define KERNEL_MIXED(name, text_a, text_b) \
+__global__ void __launch_bounds__(1024, 8) name(float* out, int iterations, float b, float c) { \
+	float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+	for (int i = 0; i != iterations; ++i) { OP8_MIXED(text_a, text_b) OP8_MIXED(text_a, text_b) OP8_MIXED(text_a, text_b) OP8_MIXED(text_a, text_b) } \
+	out[blockIdx.x * 1024 + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)); \
+}
+KERNEL_MIXED(k_mix_fma_cndmask, "v_fma_f32 %0, %1, %2, %0", "v_cndmask_b32_e64 %0, %1, %0, s[10:11]")
+KERNEL_MIXED(k_mix_fma_cvt, "v_fma_f32 %0, %1, %2, %0", "v_cvt_f32_ubyte0 %0, %1")
+KERNEL_MIXED(k_mix_fma_max3, "v_fma_f32 %0, %1, %2, %0", "v_max3_f32 %0, %1, %2, %0")
+KERNEL_MIXED(k_mix_cndmask_cvt, "v_cndmask_b32_e64 %0, %1, %0, s[10:11]", "v_cvt_f32_ubyte0 %0, %1")
+KERNEL_MIXED(k_mix_fma_rcp, "v_fma_f32 %0, %1, %2, %0", "v_rcp_f32 %0, %0")
+KERNEL_MIXED(k_mix_max3_rcp, "v_max3_f32 %0, %1, %2, %0", "v_rcp_f32 %0, %0")
+KERNEL_MIXED(k_mix_fma_add, "v_fma_f32 %0, %1, %2, %0", "v_add_f32 %0, %1, %0")
+KERNEL_MIXED(k_mix_fma_and, "v_fma_f32 %0, %1, %2, %0", "v_and_b32 %0, %1, %0")
+
 // Packed single precision: two results per lane and instruction
 #define OP8P(text) \
 	asm volatile(text : "+v"(p0) : "v"(pb), "v"(pc) : "vcc", "s10", "s11"); asm volatile(text : "+v"(p1) : "v"(pb), "v"(pc) : "vcc", "s10", "s11"); \
@@ -124,6 +145,7 @@ int main() {
 		CASE(k_rcp), CASE(k_sqrt), CASE(k_rsq), CASE(k_div_fixup), CASE(k_div_scale), CASE(k_div_fmas), CASE(k_mov), CASE(k_perm), CASE(k_bitop3), CASE(k_mbcnt),
 		CASE(k_bitop3_select), CASE(k_bfi), CASE(k_alignbit), CASE(k_or), CASE(k_lshr), CASE(k_sub_u32), CASE(k_min), CASE(k_fmac), CASE(k_lshl_or), CASE(k_mul_u32_u24),
 		CASE(k_not), CASE(k_max_u32), CASE(k_cvt_i32_f32), CASE(k_floor), CASE(k_fract), CASE(k_add_f32_e64_neg), CASE(k_ldexp), CASE(k_exp), CASE(k_log), CASE(k_sin), CASE(k_add_co),
+		CASE(k_mix_fma_cndmask), CASE(k_mix_fma_cvt), CASE(k_mix_fma_max3), CASE(k_mix_cndmask_cvt), CASE(k_mix_fma_rcp), CASE(k_mix_max3_rcp), CASE(k_mix_fma_add), CASE(k_mix_fma_and),
 		CASE(k_fma_abs), CASE(k_mul_e64), CASE(k_pk_fma), CASE(k_pk_mul), CASE(k_pk_add),
 	};
 	printf("%d CUs, %d MHz nominal; cycles are SIMD cycles per wave64 instruction with 8 waves per SIMD at the nominal clock\n", cu_count, clock_khz / 1000);

@@ -1,7 +1,8 @@
 // Persistent closest-hit traversal for gfx950 (device code only).
 //
 // One ray per lane walks the 8-wide BVH exactly like pt_trace_closest() in
-// pt_trace.h (same box test, same triangle arithmetic, same tie break, hence
+// pt_trace.h (a box test that is conservative like the one there, the same
+// triangle arithmetic, the same tie break, hence
 // bit-identical hits), organised for 64-lane waves:
 //   * Waves are persistent. A lane whose ray is complete does not wait for
 //     the slowest ray of its wave: when enough lanes are idle the wave
@@ -321,7 +322,11 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 						float cdx = (fabsf(d.x) > 1.0e-30f) ? d.x : copysignf(1.0e-30f, d.x);
 						float cdy = (fabsf(d.y) > 1.0e-30f) ? d.y : copysignf(1.0e-30f, d.y);
 						float cdz = (fabsf(d.z) > 1.0e-30f) ? d.z : copysignf(1.0e-30f, d.z);
-						idx = 1.0f / cdx; idy = 1.0f / cdy; idz = 1.0f / cdz;
+						// The reciprocals only serve the box test, which errs on the side
+						// of a hit: the hardware's reciprocal (one unit in the last place,
+						// one instruction where the correctly rounded quotient takes
+						// twelve) is paid for with twice the slack of pt_box_test_slack()
+						idx = __builtin_amdgcn_rcpf(cdx); idy = __builtin_amdgcn_rcpf(cdy); idz = __builtin_amdgcn_rcpf(cdz);
 						neg_x = (cdx < 0.0f) ? 0xffffffffu : 0u;
 						neg_y = (cdy < 0.0f) ? 0xffffffffu : 0u;
 						neg_z = (cdz < 0.0f) ? 0xffffffffu : 0u;
@@ -393,7 +398,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				float dx = pt_as_float(w0.x) - origin.x, dy = pt_as_float(w0.y) - origin.y, dz = pt_as_float(w0.z) - origin.z;
 				float bx = dx * idx, by = dy * idy, bz = dz * idz;
 				// Near planes a little nearer, far planes a little farther (pt_box_test_slack())
-				float slack = pt_box_test_slack(dx, dy, dz, sx, sy, sz);
+				float slack = 2.0f * pt_box_test_slack(dx, dy, dz, sx, sy, sz);
 				float ex = slack * fabsf(idx), ey = slack * fabsf(idy), ez = slack * fabsf(idz);
 				float bxn = bx - ex, byn = by - ey, bzn = bz - ez, bxf = bx + ex, byf = by + ey, bzf = bz + ez;
 				// Near and far planes per axis, chosen once per node by the ray's signs

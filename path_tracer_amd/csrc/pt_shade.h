@@ -709,13 +709,25 @@ PT_FN float pt_light_node_weight(const f32x4* nodes, uint32_t node, v3 shading_p
 	return center_power.w / fmaxf(dot(center_dir, center_dir), half_radius.w);
 }
 
+// The leaf that a descent of pt_sample_lights_tree() arrived at (0: none) and
+// the probability of arriving there. The density of the sampled direction
+// needs that probability again (pt_light_tree_probability() recomputes it by
+// the same arithmetic, level by level): kept, it saves that loop for the one
+// light that nearly every vertex meets.
+struct PtLightTreeSample {
+	uint32_t leaf;
+	float probability;
+};
+
 // Chooses a light by one descent and samples its cone like
 // pt_sample_spherical_light(). out_density receives the chosen light's share
 // of the density of the returned direction (selection probability times cone
 // density); it is zero and the direction is the zero vector if no light was
 // sampled.
-PT_FN v3 pt_sample_lights_tree(const PtSceneView& scene, float* out_density, v3 shading_pos, v3 normal, v2 randoms) {
+PT_FN v3 pt_sample_lights_tree(const PtSceneView& scene, float* out_density, PtLightTreeSample* out_sample, v3 shading_pos, v3 normal, v2 randoms) {
 	*out_density = 0.0f;
+	out_sample->leaf = 0;
+	out_sample->probability = 0.0f;
 	uint32_t node = 1;
 	float probability = 1.0f;
 	while (node < scene.light_leaf_count) {
@@ -732,6 +744,8 @@ PT_FN v3 pt_sample_lights_tree(const PtSceneView& scene, float* out_density, v3 
 		probability *= weight / total;
 		node = 2 * node + (left ? 0u : 1u);
 	}
+	out_sample->leaf = node;
+	out_sample->probability = probability;
 	f32x4 light = scene.tree_lights[node - scene.light_leaf_count];
 	float importance = pt_spherical_light_importance(light, shading_pos, normal);
 	if (!(importance > 0.0f))
@@ -796,7 +810,7 @@ struct PtLightLeaves {
 
 // Adds the share of a leaf's light to the densities of the rays that meet the
 // light (the test of pathtrace.frag.glsl:160-170)
-PT_FN void pt_light_leaf_density(const PtSceneView& scene, uint32_t node, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float& density_0, float& density_1) {
+PT_FN void pt_light_leaf_density(const PtSceneView& scene, const PtLightTreeSample& sample, uint32_t node, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float& density_0, float& density_1) {
 	f32x4 light = scene.tree_lights[node - scene.light_leaf_count];
 	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
 	float center_dist_2 = dot(center_dir, center_dir);
@@ -808,18 +822,19 @@ PT_FN void pt_light_leaf_density(const PtSceneView& scene, uint32_t node, v3 sha
 	if (hit_0 || hit_1) {
 		float importance = pt_spherical_light_importance(light, shading_pos, normal);
 		if (importance > 0.0f) {
-			float density = pt_light_tree_probability(scene, node, shading_pos, normal) / ((2.0f * PT_PI) * importance);
+			float selection = (node == sample.leaf) ? sample.probability : pt_light_tree_probability(scene, node, shading_pos, normal);
+			float density = selection / ((2.0f * PT_PI) * importance);
 			density_0 += hit_0 ? density : 0.0f;
 			density_1 += hit_1 ? density : 0.0f;
 		}
 	}
 }
 
-PT_FN void pt_light_leaves_flush(const PtSceneView& scene, PtLightLeaves& leaves, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float& density_0, float& density_1) {
-	if (leaves.count > 0) pt_light_leaf_density(scene, leaves.node_0, shading_pos, normal, dir_0, dir_1, density_0, density_1);
-	if (leaves.count > 1) pt_light_leaf_density(scene, leaves.node_1, shading_pos, normal, dir_0, dir_1, density_0, density_1);
-	if (leaves.count > 2) pt_light_leaf_density(scene, leaves.node_2, shading_pos, normal, dir_0, dir_1, density_0, density_1);
-	if (leaves.count > 3) pt_light_leaf_density(scene, leaves.node_3, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+PT_FN void pt_light_leaves_flush(const PtSceneView& scene, const PtLightTreeSample& sample, PtLightLeaves& leaves, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float& density_0, float& density_1) {
+	if (leaves.count > 0) pt_light_leaf_density(scene, sample, leaves.node_0, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+	if (leaves.count > 1) pt_light_leaf_density(scene, sample, leaves.node_1, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+	if (leaves.count > 2) pt_light_leaf_density(scene, sample, leaves.node_2, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+	if (leaves.count > 3) pt_light_leaf_density(scene, sample, leaves.node_3, shading_pos, normal, dir_0, dir_1, density_0, density_1);
 	leaves.count = 0;
 }
 
@@ -840,7 +855,7 @@ PT_FN bool pt_light_tree_visit(const PtSceneView& scene, uint32_t node, const Pt
 // subtree is entered when one of the rays meets its box. Both children of a
 // node are looked at together; a right child still to be entered is remembered
 // as one bit per tree level (the node index itself tells the way back).
-PT_FN void pt_lights_density_tree_2(const PtSceneView& scene, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float* out_density_0, float* out_density_1) {
+PT_FN void pt_lights_density_tree_2(const PtSceneView& scene, const PtLightTreeSample& sample, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float* out_density_0, float* out_density_1) {
 	float density_0 = 0.0f, density_1 = 0.0f;
 	PtSlabRay ray_0 = pt_slab_ray(shading_pos, dir_0), ray_1 = pt_slab_ray(shading_pos, dir_1);
 	f32x4 root_center = scene.light_nodes[2], root_half = scene.light_nodes[3];
@@ -864,7 +879,7 @@ PT_FN void pt_lights_density_tree_2(const PtSceneView& scene, v3 shading_pos, v3
 			for (uint32_t child = 0; child != 2; ++child) {
 				if (child ? enter_1 : enter_0) {
 					if (leaves.count == 4)
-						pt_light_leaves_flush(scene, leaves, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+						pt_light_leaves_flush(scene, sample, leaves, shading_pos, normal, dir_0, dir_1, density_0, density_1);
 					uint32_t leaf = 2 * node + child;
 					if (leaves.count == 0) leaves.node_0 = leaf;
 					else if (leaves.count == 1) leaves.node_1 = leaf;
@@ -890,7 +905,7 @@ PT_FN void pt_lights_density_tree_2(const PtSceneView& scene, v3 shading_pos, v3
 		else
 			inside = false;
 	}
-	pt_light_leaves_flush(scene, leaves, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+	pt_light_leaves_flush(scene, sample, leaves, shading_pos, normal, dir_0, dir_1, density_0, density_1);
 	*out_density_0 = density_0;
 	*out_density_1 = density_1;
 }
@@ -972,8 +987,11 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		// light's random numbers are drawn before the BRDF's, as in the
 		// reference) so that one loop over the lights yields both densities.
 		float total_light_importance = 0.0f, sampled_light_density = 0.0f;
+		PtLightTreeSample tree_sample;
+		tree_sample.leaf = 0;
+		tree_sample.probability = 0.0f;
 		v3 light_dir = (strategy == PT_STRATEGY_NEE_TREE)
-			? pt_sample_lights_tree(scene, &sampled_light_density, s.pos, s.normal, pt_random(sx, sy))
+			? pt_sample_lights_tree(scene, &sampled_light_density, &tree_sample, s.pos, s.normal, pt_random(sx, sy))
 			: pt_sample_lights(scene, light_cache, &total_light_importance, s.pos, s.normal, pt_random(sx, sy));
 		float lambert_in_0 = dot(s.normal, light_dir);
 		r.next_dir = pt_sample_frostbite_brdf(s, pt_random(sx, sy));
@@ -981,7 +999,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		float light_density_0 = 0.0f, light_density_1 = 0.0f;
 		if (lambert_in_0 > 0.0f || lambert_in_1 > 0.0f) {
 			if (strategy == PT_STRATEGY_NEE_TREE) {
-				pt_lights_density_tree_2(scene, s.pos, s.normal, light_dir, r.next_dir, &light_density_0, &light_density_1);
+				pt_lights_density_tree_2(scene, tree_sample, s.pos, s.normal, light_dir, r.next_dir, &light_density_0, &light_density_1);
 				// Like max(1, count) at pathtrace.frag.glsl:172-173: the sampled
 				// light counts even if rounding lets its own ray miss it
 				light_density_0 = fmaxf(light_density_0, sampled_light_density);

@@ -1,6 +1,7 @@
-/* Minimal image encoders for screenshots: Radiance RGBE (*.hdr) and PNG with
- * stored (uncompressed) deflate blocks. They take the place of the vendored
- * stb_image_write.h in the reference (src/main.c:2053, :2077). */
+/* Image encoders for screenshots: Radiance RGBE (*.hdr), PNG (filtered
+ * scanlines, deflate with fixed Huffman codes) and baseline JPEG. They take
+ * the place of the vendored stb_image_write.h in the reference
+ * (src/main.c:2053, :2077). */
 #include "pt_host.h"
 #include <math.h>
 #include <stdio.h>
@@ -71,11 +72,182 @@ static void write_chunk(FILE* file, const char* type, const uint8_t* data, uint3
 	fwrite(tail, 1, 4, file);
 }
 
+/* ---- Deflate (RFC 1951) with the fixed Huffman codes and greedy LZ77
+ * matching over hash chains, enough for screenshots: smooth images shrink to a
+ * fraction, noise grows by an eighth at worst. ---- */
+typedef struct {
+	uint8_t* data;
+	size_t size;
+	uint32_t bit_buffer;
+	int bit_count;
+} deflate_writer_t;
+
+/* Bits are packed starting from the least significant bit of each byte */
+static void deflate_put_bits(deflate_writer_t* w, uint32_t bits, int count) {
+	w->bit_buffer |= bits << w->bit_count;
+	w->bit_count += count;
+	while (w->bit_count >= 8) {
+		w->data[w->size++] = (uint8_t) w->bit_buffer;
+		w->bit_buffer >>= 8;
+		w->bit_count -= 8;
+	}
+}
+
+/* Huffman codes go out starting from their most significant bit */
+static void deflate_put_code(deflate_writer_t* w, uint32_t code, int length) {
+	uint32_t reversed = 0;
+	for (int i = 0; i != length; ++i)
+		reversed |= ((code >> i) & 1u) << (length - 1 - i);
+	deflate_put_bits(w, reversed, length);
+}
+
+/* A literal byte or a length symbol (256: end of block) in the fixed code */
+static void deflate_put_symbol(deflate_writer_t* w, uint32_t symbol) {
+	if (symbol < 144) deflate_put_code(w, 0x30 + symbol, 8);
+	else if (symbol < 256) deflate_put_code(w, 0x190 + (symbol - 144), 9);
+	else if (symbol < 280) deflate_put_code(w, symbol - 256, 7);
+	else deflate_put_code(w, 0xc0 + (symbol - 280), 8);
+}
+
+static const uint16_t deflate_length_base[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+static const uint8_t deflate_length_extra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+static const uint16_t deflate_distance_base[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+static const uint8_t deflate_distance_extra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+
+static void deflate_put_match(deflate_writer_t* w, uint32_t length, uint32_t distance) {
+	int l = 28;
+	while (deflate_length_base[l] > length) --l;
+	deflate_put_symbol(w, 257 + (uint32_t) l);
+	deflate_put_bits(w, length - deflate_length_base[l], deflate_length_extra[l]);
+	int d = 29;
+	while (deflate_distance_base[d] > distance) --d;
+	deflate_put_code(w, (uint32_t) d, 5);
+	deflate_put_bits(w, distance - deflate_distance_base[d], deflate_distance_extra[d]);
+}
+
+/* Compresses size bytes into a zlib stream (RFC 1950); the caller frees the
+ * result. Returns NULL if memory runs out. */
+static uint8_t* zlib_compress(const uint8_t* raw, size_t size, size_t* out_size) {
+	enum { WINDOW = 32768, HASH_SIZE = 1 << 15, MAX_CHAIN = 32, MIN_MATCH = 3, MAX_MATCH = 258 };
+	deflate_writer_t w;
+	/* Nine bits per byte at worst, plus header, end of block and checksum */
+	w.data = malloc(size + size / 8 + 64);
+	int32_t* head = malloc(sizeof(int32_t) * HASH_SIZE);
+	int32_t* previous = malloc(sizeof(int32_t) * WINDOW);
+	if (!w.data || !head || !previous || size > 0x7fffffff) {
+		free(w.data); free(head); free(previous);
+		return NULL;
+	}
+	w.size = 0; w.bit_buffer = 0; w.bit_count = 0;
+	w.data[w.size++] = 0x78; w.data[w.size++] = 0x9c;
+	deflate_put_bits(&w, 1, 1); /* last block */
+	deflate_put_bits(&w, 1, 2); /* fixed Huffman codes */
+	for (int i = 0; i != HASH_SIZE; ++i) head[i] = -1;
+	size_t position = 0;
+	while (position < size) {
+		uint32_t best_length = 0, best_distance = 0;
+		if (position + MIN_MATCH <= size) {
+			uint32_t hash = ((uint32_t) raw[position] << 10 ^ (uint32_t) raw[position + 1] << 5 ^ raw[position + 2]) & (HASH_SIZE - 1);
+			int32_t candidate = head[hash];
+			size_t limit = size - position;
+			if (limit > MAX_MATCH) limit = MAX_MATCH;
+			for (int chain = 0; chain != MAX_CHAIN && candidate >= 0 && position - (size_t) candidate <= WINDOW; ++chain) {
+				uint32_t length = 0;
+				while (length < limit && raw[(size_t) candidate + length] == raw[position + length]) ++length;
+				if (length > best_length) {
+					best_length = length;
+					best_distance = (uint32_t) (position - (size_t) candidate);
+					if (length == limit) break;
+				}
+				int32_t next = previous[candidate & (WINDOW - 1)];
+				/* Chains end where an entry has been overwritten by a later position */
+				if (next >= candidate) break;
+				candidate = next;
+			}
+		}
+		size_t step = 1;
+		if (best_length >= MIN_MATCH) {
+			deflate_put_match(&w, best_length, best_distance);
+			step = best_length;
+		}
+		else
+			deflate_put_symbol(&w, raw[position]);
+		/* Enter the positions passed into the hash chains */
+		for (size_t i = 0; i != step; ++i, ++position) {
+			if (position + MIN_MATCH <= size) {
+				uint32_t hash = ((uint32_t) raw[position] << 10 ^ (uint32_t) raw[position + 1] << 5 ^ raw[position + 2]) & (HASH_SIZE - 1);
+				previous[position & (WINDOW - 1)] = head[hash];
+				head[hash] = (int32_t) position;
+			}
+		}
+	}
+	deflate_put_symbol(&w, 256);
+	if (w.bit_count)
+		deflate_put_bits(&w, 0, 8 - w.bit_count);
+	uint32_t a = 1, b = 0;
+	for (size_t i = 0; i != size; ++i) {
+		a = (a + raw[i]) % 65521u;
+		b = (b + a) % 65521u;
+	}
+	put_be32(&w.data[w.size], (b << 16) | a);
+	w.size += 4;
+	free(head); free(previous);
+	*out_size = w.size;
+	return w.data;
+}
+
+static int paeth(int a, int b, int c) {
+	int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+	return (pa <= pb && pa <= pc) ? a : ((pb <= pc) ? b : c);
+}
+
 int write_png(const char* file_path, uint32_t width, uint32_t height, const uint8_t* rgb) {
 	init_crc_table();
-	FILE* file = fopen(file_path, "wb");
-	if (!file)
+	size_t row_bytes = 3 * (size_t) width, stride = 1 + row_bytes;
+	if (width == 0 || height == 0 || stride * (double) height > 2.0e9)
 		return 1;
+	/* Scanlines, each with the filter (none, sub, up, average, Paeth) that
+	 * leaves the smallest sum of absolute residuals */
+	uint8_t* raw = malloc(stride * height);
+	uint8_t* candidate = malloc(row_bytes);
+	if (!raw || !candidate) {
+		free(raw); free(candidate);
+		return 1;
+	}
+	for (uint32_t y = 0; y != height; ++y) {
+		const uint8_t* row = &rgb[row_bytes * y];
+		const uint8_t* above = y ? &rgb[row_bytes * (y - 1)] : NULL;
+		uint8_t* out = &raw[stride * y];
+		uint64_t best_cost = ~0ull;
+		for (int filter = 0; filter != 5; ++filter) {
+			uint64_t cost = 0;
+			for (size_t i = 0; i != row_bytes; ++i) {
+				int left = (i >= 3) ? row[i - 3] : 0, up = above ? above[i] : 0, up_left = (above && i >= 3) ? above[i - 3] : 0;
+				int predicted = (filter == 0) ? 0 : (filter == 1) ? left : (filter == 2) ? up : (filter == 3) ? (left + up) / 2 : paeth(left, up, up_left);
+				uint8_t residual = (uint8_t) (row[i] - predicted);
+				candidate[i] = residual;
+				cost += (residual < 128) ? residual : 256 - residual;
+			}
+			if (cost < best_cost) {
+				best_cost = cost;
+				out[0] = (uint8_t) filter;
+				memcpy(out + 1, candidate, row_bytes);
+			}
+		}
+	}
+	free(candidate);
+	size_t zsize = 0;
+	uint8_t* z = zlib_compress(raw, stride * height, &zsize);
+	free(raw);
+	if (!z || zsize > 0x7fffffffu) {
+		free(z);
+		return 1;
+	}
+	FILE* file = fopen(file_path, "wb");
+	if (!file) {
+		free(z);
+		return 1;
+	}
 	static const uint8_t signature[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
 	fwrite(signature, 1, 8, file);
 	uint8_t ihdr[13];
@@ -83,40 +255,7 @@ int write_png(const char* file_path, uint32_t width, uint32_t height, const uint
 	put_be32(ihdr + 4, height);
 	ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
 	write_chunk(file, "IHDR", ihdr, 13);
-	/* Raw scanlines with filter type 0, wrapped into stored deflate blocks */
-	size_t stride = 1 + 3 * (size_t) width;
-	size_t raw_size = stride * height;
-	size_t block_count = (raw_size + 65534) / 65535;
-	if (block_count == 0) block_count = 1;
-	size_t zsize = 2 + raw_size + 5 * block_count + 4;
-	if (zsize > 0x7fffffffu) {
-		fclose(file);
-		return 1;
-	}
-	uint8_t* z = malloc(zsize);
-	size_t o = 0;
-	z[o++] = 0x78; z[o++] = 0x01;
-	uint32_t a = 1, b = 0;
-	size_t done = 0;
-	for (size_t block = 0; block != block_count; ++block) {
-		size_t n = raw_size - done;
-		if (n > 65535) n = 65535;
-		z[o++] = (block + 1 == block_count) ? 1 : 0;
-		z[o++] = (uint8_t) n; z[o++] = (uint8_t) (n >> 8);
-		z[o++] = (uint8_t) ~n; z[o++] = (uint8_t) (~n >> 8);
-		for (size_t i = 0; i != n; ++i) {
-			size_t pos = done + i;
-			size_t y = pos / stride, x = pos % stride;
-			uint8_t v = (x == 0) ? 0 : rgb[3 * y * (size_t) width + (x - 1)];
-			z[o++] = v;
-			a = (a + v) % 65521u;
-			b = (b + a) % 65521u;
-		}
-		done += n;
-	}
-	put_be32(&z[o], (b << 16) | a);
-	o += 4;
-	write_chunk(file, "IDAT", z, (uint32_t) o);
+	write_chunk(file, "IDAT", z, (uint32_t) zsize);
 	write_chunk(file, "IEND", NULL, 0);
 	free(z);
 	return fclose(file) != 0;

@@ -153,9 +153,20 @@ def test_image_writers(tmp_path):
     path = str(tmp_path / "a.png")
     assert host_api.lib().write_png(os.fsencode(path), 53, 37, rgb.ctypes.data_as(C.c_void_p)) == 0
     assert (np.asarray(Image.open(path)) == rgb).all()
-    big = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)  # more than one stored deflate block
+    big = rng.integers(0, 256, (300, 400, 3), dtype=np.uint8)  # noise: literals only, longer than the match window
     assert host_api.lib().write_png(os.fsencode(path), 400, 300, big.ctypes.data_as(C.c_void_p)) == 0
     assert (np.asarray(Image.open(path)) == big).all()
+    # Gradients, flat areas and repeated tiles exercise filters and matches of every length and distance class
+    y, x = np.mgrid[0:300, 0:400]
+    smooth = np.stack([x * 255 // 399, y * 255 // 299, (x + y) * 255 // 698], axis=2).astype(np.uint8)
+    tiles = np.tile(rng.integers(0, 256, (7, 5, 3), dtype=np.uint8), (60, 90, 1))
+    far = np.concatenate([big[:40], smooth[:100], big[:40]])  # the second copy of the noise lies beyond the 32 KB window
+    for image, largest in ((smooth, 20000), (tiles, 20000), (np.full((64, 64, 3), 77, np.uint8), 400), (rng.integers(0, 256, (1, 1, 3), dtype=np.uint8), 100),
+                           (rng.integers(0, 4, (1000, 3, 3), dtype=np.uint8), 9000), (far, far.nbytes * 9 // 8)):
+        image = np.ascontiguousarray(image)
+        assert host_api.lib().write_png(os.fsencode(path), image.shape[1], image.shape[0], image.ctypes.data_as(C.c_void_p)) == 0
+        assert (np.asarray(Image.open(path)) == image).all()
+        assert os.path.getsize(path) <= largest
     hdr = (rng.random((20, 30, 3)) * np.array([0.01, 5.0, 300.0])).astype(np.float32)
     hdr[0, 0] = 0
     path = str(tmp_path / "a.hdr")

@@ -1117,8 +1117,12 @@ static float light_selection_probability(const context_t* ctx, uint32_t leaf_nod
 }
 
 /* Adds to *density, for every light below node that a ray from shading_pos
-   along dir meets (test of :160-170), selection probability times cone
-   density; left subtree first */
+   along dir meets, selection probability times cone density; left subtree
+   first. The test is the condition of :160-170 with the distance between the
+   light's centre and the line taken from a cross product: the reference's
+   discriminant, a difference of two squared distances, is off by about a
+   thousandth of the distance to the light, more than the boxes of the tree
+   allow for. */
 static void accumulate_tree_density(const context_t* ctx, uint32_t node, vec3 shading_pos, vec3 normal, vec3 dir, float* density) {
 	const float* n = &ctx->light_nodes[8 * (size_t) node];
 	if (!(n[3] > 0.0f))
@@ -1126,11 +1130,11 @@ static void accumulate_tree_density(const context_t* ctx, uint32_t node, vec3 sh
 	if (node >= ctx->light_leaf_count) {
 		const float* l = &ctx->tree_lights[4 * (size_t) (node - ctx->light_leaf_count)];
 		vec3 center_dir = sub3(v3(l[0], l[1], l[2]), shading_pos);
-		float center_dist_2 = dot3(center_dir, center_dir);
+		float in_sphere = dot3(center_dir, center_dir) - l[3] * l[3];
 		float center_dot_dir = dot3(center_dir, dir);
-		float in_sphere = center_dist_2 - l[3] * l[3];
-		float discriminant = center_dot_dir * center_dot_dir - in_sphere;
-		if (discriminant >= 0.0f && in_sphere >= 0.0f && center_dot_dir >= 0.0f) {
+		vec3 lever = cross3(center_dir, dir);
+		float length_2 = dot3(dir, dir);
+		if (dot3(lever, lever) <= (l[3] * l[3]) * length_2 && length_2 > 0.0f && in_sphere >= 0.0f && center_dot_dir >= 0.0f) {
 			float importance = get_spherical_light_importance(v3(l[0], l[1], l[2]), l[3], shading_pos, normal);
 			if (importance > 0.0f)
 				*density += light_selection_probability(ctx, node, shading_pos, normal) / ((2.0f * M_PI_F) * importance);

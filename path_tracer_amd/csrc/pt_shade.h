@@ -808,17 +808,27 @@ struct PtLightLeaves {
 	uint32_t node_0, node_1, node_2, node_3, count;
 };
 
+// Whether the ray from shading_pos along dir meets the light and starts
+// outside of it: the condition of pathtrace.frag.glsl:160-170, but with the
+// distance between the light's centre and the line taken from a cross product.
+// The reference's discriminant subtracts two squared distances and is off by
+// about a thousandth of the distance to the light, which no box or grid over
+// the lights could follow; this form is off by a few millionths of the
+// coordinates involved and holds for directions of any length.
+PT_FN bool pt_ray_meets_light(f32x4 light, v3 shading_pos, v3 dir) {
+	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
+	float in_sphere = dot(center_dir, center_dir) - light.w * light.w;
+	float center_dot_dir = dot(center_dir, dir);
+	v3 lever = cross(center_dir, dir);
+	float length_2 = dot(dir, dir);
+	return dot(lever, lever) <= (light.w * light.w) * length_2 && length_2 > 0.0f && in_sphere >= 0.0f && center_dot_dir >= 0.0f;
+}
+
 // Adds the share of a leaf's light to the densities of the rays that meet the
-// light (the test of pathtrace.frag.glsl:160-170)
+// light
 PT_FN void pt_light_leaf_density(const PtSceneView& scene, const PtLightTreeSample& sample, uint32_t node, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float& density_0, float& density_1) {
 	f32x4 light = scene.tree_lights[node - scene.light_leaf_count];
-	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
-	float center_dist_2 = dot(center_dir, center_dir);
-	float in_sphere = center_dist_2 - light.w * light.w;
-	float center_dot_dir_0 = dot(center_dir, dir_0), center_dot_dir_1 = dot(center_dir, dir_1);
-	float discriminant_0 = center_dot_dir_0 * center_dot_dir_0 - in_sphere, discriminant_1 = center_dot_dir_1 * center_dot_dir_1 - in_sphere;
-	bool hit_0 = discriminant_0 >= 0.0f && in_sphere >= 0.0f && center_dot_dir_0 >= 0.0f;
-	bool hit_1 = discriminant_1 >= 0.0f && in_sphere >= 0.0f && center_dot_dir_1 >= 0.0f;
+	bool hit_0 = pt_ray_meets_light(light, shading_pos, dir_0), hit_1 = pt_ray_meets_light(light, shading_pos, dir_1);
 	if (hit_0 || hit_1) {
 		float importance = pt_spherical_light_importance(light, shading_pos, normal);
 		if (importance > 0.0f) {

@@ -39,6 +39,10 @@ def lib():
         _lib.emu_destroy_scene.argtypes = [C.c_void_p]
         _lib.emu_set_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         _lib.emu_bvh_info.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.emu_lights_density.restype = None
+        _lib.emu_lights_density.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        _lib.emu_light_tree_reuse_mismatches.restype = C.c_uint32
+        _lib.emu_light_tree_reuse_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
         _lib.emu_binary_tree_cost.restype = C.c_double
         _lib.emu_binary_tree_cost.argtypes = [C.c_void_p]
         _lib.emu_trace_rays_brute_force.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -98,6 +102,19 @@ class EmuScene:
     def set_lights(self, lights):
         lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 4)
         lib().emu_set_lights(self.handle, _ptr(lights), len(lights))
+
+    def lights_density(self, positions, normals, directions_0, directions_1, mode):
+        """Densities of two directions per vertex under the light tree's sampling; mode 0: by the walk of the tree,
+        1: by a loop over all lights."""
+        arrays = [np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (positions, normals, directions_0, directions_1)]
+        out = np.zeros((len(arrays[0]), 2), np.float32)
+        lib().emu_lights_density(self.handle, *[_ptr(a) for a in arrays], len(arrays[0]), mode, _ptr(out))
+        return out
+
+    def light_tree_reuse_mismatches(self, positions, normals, randoms):
+        positions, normals = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (positions, normals))
+        randoms = np.ascontiguousarray(randoms, np.float32).reshape(-1, 2)
+        return int(lib().emu_light_tree_reuse_mismatches(self.handle, _ptr(positions), _ptr(normals), _ptr(randoms), len(positions)))
 
     def bvh_info(self):
         out = np.zeros(3, np.uint32)

@@ -304,6 +304,49 @@ void emu_set_lights(EmuScene* s, const float* lights, uint32_t count) {
 	pt_build_light_tree(s->light_tree, lights, count);
 }
 
+// The densities of two directions under the light tree's sampling, two ways: 0 by the walk of the tree, 1 by a loop
+// over all leaves in order (the definition)
+void emu_lights_density(EmuScene* s, const float* positions, const float* normals, const float* directions_0, const float* directions_1, uint32_t count, int mode, float* out_densities) {
+	PtSceneView view = s->view();
+	PtLightTreeSample none;
+	none.leaf = 0;
+	none.probability = 0.0f;
+	for (uint32_t i = 0; i != count; ++i) {
+		v3 pos = mk3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]), normal = mk3(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+		v3 d0 = mk3(directions_0[3 * i], directions_0[3 * i + 1], directions_0[3 * i + 2]), d1 = mk3(directions_1[3 * i], directions_1[3 * i + 1], directions_1[3 * i + 2]);
+		float density_0 = 0.0f, density_1 = 0.0f;
+		if (mode == 0)
+			pt_lights_density_tree_2(view, none, pos, normal, d0, d1, &density_0, &density_1);
+		else
+			for (uint32_t j = 0; j != s->light_tree.leaf_count; ++j)
+				if (s->light_tree.lights[j].w * s->light_tree.lights[j].w > 0.0f)
+					pt_light_leaf_density(view, none, s->light_tree.leaf_count + j, pos, normal, d0, d1, density_0, density_1);
+		out_densities[2 * i] = density_0;
+		out_densities[2 * i + 1] = density_1;
+	}
+}
+
+// Samples a light through the tree for every vertex and returns how often the density of the sampled direction
+// differs between reusing the descent's selection probability and recomputing it
+uint32_t emu_light_tree_reuse_mismatches(EmuScene* s, const float* positions, const float* normals, const float* randoms, uint32_t count) {
+	PtSceneView view = s->view();
+	uint32_t mismatches = 0;
+	for (uint32_t i = 0; i != count; ++i) {
+		v3 pos = mk3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]), normal = mk3(normals[3 * i], normals[3 * i + 1], normals[3 * i + 2]);
+		PtLightTreeSample sample, none;
+		none.leaf = 0; none.probability = 0.0f;
+		float sampled_density = 0.0f;
+		v2 r; r.x = randoms[2 * i]; r.y = randoms[2 * i + 1];
+		v3 dir = pt_sample_lights_tree(view, &sampled_density, &sample, pos, normal, r);
+		v3 other = mk3(normal.y, normal.z, normal.x);
+		float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+		pt_lights_density_tree_2(view, sample, pos, normal, dir, other, &a0, &a1);
+		pt_lights_density_tree_2(view, none, pos, normal, dir, other, &b0, &b1);
+		mismatches += pt_as_uint(a0) != pt_as_uint(b0) || pt_as_uint(a1) != pt_as_uint(b1);
+	}
+	return mismatches;
+}
+
 void emu_bvh_info(EmuScene* s, uint32_t* out) { out[0] = s->node_count; out[1] = s->depth; out[2] = s->max_stack; }
 double emu_binary_tree_cost(EmuScene* s) { return s->binary_cost; }
 

@@ -232,6 +232,19 @@ struct PtSceneView {
 	const f32x4* light_nodes;
 	const f32x4* tree_lights;
 	uint32_t light_leaf_count;
+	// A grid over the same lights, or light_grid_cells == NULL: which lights
+	// can a ray meet? Cell (x, y, z) is entry c = (z * dim[1] + y) * dim[0] + x
+	// of light_grid_cells; it lists the lights light_grid_lights[e], which are
+	// the leaves light_grid_leaves[e] of the tree, for e from light_grid_cells[c]
+	// up to light_grid_cells[c + 1]. A light is listed in every cell that its
+	// box, widened by more than rounding can amount to for rays that start
+	// within light_grid_reach (sum of absolute coordinates), touches.
+	const uint32_t* light_grid_cells;
+	const f32x4* light_grid_lights;
+	const uint32_t* light_grid_leaves;
+	float light_grid_lo[3], light_grid_cell[3], light_grid_inv_cell[3];
+	uint32_t light_grid_dim[3];
+	float light_grid_reach;
 };
 
 // Wavefront buffers. Queues are indexed by slot, path state by path index.

@@ -702,6 +702,12 @@ struct pt_scene {
 	f32x4* light_nodes;
 	f32x4* tree_lights;
 	uint32_t light_leaf_count;
+	// The grid over the lights (PtSceneView::light_grid_*), or light_grid_cells NULL
+	uint32_t* light_grid_cells;
+	f32x4* light_grid_lights;
+	uint32_t* light_grid_leaves;
+	float light_grid_lo[3], light_grid_cell[3], light_grid_inv_cell[3], light_grid_reach;
+	uint32_t light_grid_dim[3];
 	int light_sampling;
 	uint32_t light_count;
 	PtNode* nodes;
@@ -788,6 +794,16 @@ static PtSceneView pt_scene_view(const pt_scene* s) {
 	v.light_nodes = s->light_nodes;
 	v.tree_lights = s->tree_lights;
 	v.light_leaf_count = s->light_leaf_count;
+	v.light_grid_cells = s->light_grid_cells;
+	v.light_grid_lights = s->light_grid_lights;
+	v.light_grid_leaves = s->light_grid_leaves;
+	for (int a = 0; a != 3; ++a) {
+		v.light_grid_lo[a] = s->light_grid_lo[a];
+		v.light_grid_cell[a] = s->light_grid_cell[a];
+		v.light_grid_inv_cell[a] = s->light_grid_inv_cell[a];
+		v.light_grid_dim[a] = s->light_grid_dim[a];
+	}
+	v.light_grid_reach = s->light_grid_reach;
 	v.emission_material_index = s->emission_material_index;
 	return v;
 }
@@ -1142,7 +1158,7 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 	s->material_count = (uint32_t) header->material_count;
 	s->texture_count = texture_count;
 	s->positions = NULL; s->normals_uvs = NULL; s->shade_tris = NULL; s->materials = NULL; s->texture_table = NULL; s->texture_blob = NULL;
-	s->srgb_to_linear = NULL; s->lights = NULL; s->light_count = 0; s->light_nodes = NULL; s->tree_lights = NULL; s->light_leaf_count = 0; s->light_sampling = PT_LIGHT_SAMPLING_EXACT; s->nodes = NULL; s->tris = NULL;
+	s->srgb_to_linear = NULL; s->lights = NULL; s->light_count = 0; s->light_nodes = NULL; s->tree_lights = NULL; s->light_leaf_count = 0; s->light_grid_cells = NULL; s->light_grid_lights = NULL; s->light_grid_leaves = NULL; s->light_sampling = PT_LIGHT_SAMPLING_EXACT; s->nodes = NULL; s->tris = NULL;
 	memset(&s->bvh_info, 0, sizeof(s->bvh_info));
 	s->strategy = PT_STRATEGY_NEE;
 	s->path_length = 4;
@@ -1293,7 +1309,7 @@ extern "C" void pt_destroy_scene(pt_scene_t* s) {
 		hipHostFree(s->snapshot_pool[i]);
 	pt_free_render_targets(s);
 	hipFree(s->positions); hipFree(s->normals_uvs); hipFree(s->shade_tris); hipFree(s->materials); hipFree(s->texture_table); hipFree(s->texture_blob);
-	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->light_nodes); hipFree(s->tree_lights); hipFree(s->nodes); hipFree(s->tris);
+	hipFree(s->srgb_to_linear); hipFree(s->lights); hipFree(s->light_nodes); hipFree(s->tree_lights); hipFree(s->light_grid_cells); hipFree(s->light_grid_lights); hipFree(s->light_grid_leaves); hipFree(s->nodes); hipFree(s->tris);
 	hipFree(s->counters); hipFree(s->constants); hipFree(s->visit_counters); hipFree(s->error_word); hipFree(s->stack_overflow); hipFree(s->stack_overflow_shadow);
 	if (s->shade_done) hipEventDestroy(s->shade_done);
 	if (s->shadow_done) hipEventDestroy(s->shadow_done);
@@ -1313,19 +1329,44 @@ static int pt_set_lights_impl(pt_scene_t* s, const float* lights, uint32_t count
 	// and changes only here
 	PtLightTree tree;
 	pt_build_light_tree(tree, lights, count);
+	PtLightGrid grid;
+#ifndef PT_LIGHTS_PER_CELL
+// Lights per cell of the grid over the lights, on average. Shading 10 000
+// lights takes 14.7 / 14.5 / 14.8 ms with 0.25 / 0.5 / 1 (smaller cells: more
+// steps per ray, fewer lights to test per step).
+#define PT_LIGHTS_PER_CELL 0.5f
+#endif
+	pt_build_light_grid(grid, tree, PT_LIGHTS_PER_CELL);
 	f32x4* fresh = NULL;
 	f32x4* fresh_nodes = NULL;
 	f32x4* fresh_tree_lights = NULL;
+	uint32_t* fresh_cells = NULL;
+	f32x4* fresh_grid_lights = NULL;
+	uint32_t* fresh_grid_leaves = NULL;
 	if (pt_alloc(&fresh, count) || pt_alloc(&fresh_nodes, tree.nodes.size()) || pt_alloc(&fresh_tree_lights, tree.lights.size())
 		|| (count && hipMemcpy(fresh, lights, sizeof(float) * 4 * count, hipMemcpyHostToDevice) != hipSuccess)
 		|| hipMemcpy(fresh_nodes, tree.nodes.data(), sizeof(f32x4) * tree.nodes.size(), hipMemcpyHostToDevice) != hipSuccess
-		|| hipMemcpy(fresh_tree_lights, tree.lights.data(), sizeof(f32x4) * tree.lights.size(), hipMemcpyHostToDevice) != hipSuccess)
+		|| hipMemcpy(fresh_tree_lights, tree.lights.data(), sizeof(f32x4) * tree.lights.size(), hipMemcpyHostToDevice) != hipSuccess
+		|| (grid.valid && (pt_alloc(&fresh_cells, grid.cells.size()) || pt_alloc(&fresh_grid_lights, grid.lights.size()) || pt_alloc(&fresh_grid_leaves, grid.leaves.size())
+			|| hipMemcpy(fresh_cells, grid.cells.data(), sizeof(uint32_t) * grid.cells.size(), hipMemcpyHostToDevice) != hipSuccess
+			|| hipMemcpy(fresh_grid_lights, grid.lights.data(), sizeof(f32x4) * grid.lights.size(), hipMemcpyHostToDevice) != hipSuccess
+			|| hipMemcpy(fresh_grid_leaves, grid.leaves.data(), sizeof(uint32_t) * grid.leaves.size(), hipMemcpyHostToDevice) != hipSuccess)))
 	{
 		printf("Failed to upload %u lights.\n", count);
-		hipFree(fresh); hipFree(fresh_nodes); hipFree(fresh_tree_lights);
+		hipFree(fresh); hipFree(fresh_nodes); hipFree(fresh_tree_lights); hipFree(fresh_cells); hipFree(fresh_grid_lights); hipFree(fresh_grid_leaves);
 		return 1;
 	}
-	hipFree(s->lights); hipFree(s->light_nodes); hipFree(s->tree_lights);
+	hipFree(s->lights); hipFree(s->light_nodes); hipFree(s->tree_lights); hipFree(s->light_grid_cells); hipFree(s->light_grid_lights); hipFree(s->light_grid_leaves);
+	s->light_grid_cells = fresh_cells;
+	s->light_grid_lights = fresh_grid_lights;
+	s->light_grid_leaves = fresh_grid_leaves;
+	for (int a = 0; a != 3; ++a) {
+		s->light_grid_lo[a] = grid.lo[a];
+		s->light_grid_cell[a] = grid.cell[a];
+		s->light_grid_inv_cell[a] = grid.inv_cell[a];
+		s->light_grid_dim[a] = grid.dim[a];
+	}
+	s->light_grid_reach = grid.reach;
 	s->lights = fresh;
 	s->light_count = count;
 	s->light_nodes = fresh_nodes;

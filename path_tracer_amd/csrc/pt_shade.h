@@ -859,13 +859,188 @@ PT_FN bool pt_light_tree_visit(const PtSceneView& scene, uint32_t node, const Pt
 	return center_power.w > 0.0f && (pt_ray_meets_box(ray_0, center, half) || pt_ray_meets_box(ray_1, center, half));
 }
 
+// Up to four leaves in ascending order (unused slots hold 0xffffffff); a fifth
+// sets overflow
+struct PtLeafSet {
+	uint32_t leaf_0, leaf_1, leaf_2, leaf_3, count;
+	bool overflow;
+};
+
+PT_FN void pt_leaf_set_insert(PtLeafSet& set, uint32_t leaf) {
+	if (leaf == set.leaf_0 || leaf == set.leaf_1 || leaf == set.leaf_2 || leaf == set.leaf_3)
+		return;
+	if (set.count == 4) {
+		set.overflow = true;
+		return;
+	}
+	// Into the last slot, which is free, then down to its place
+	set.leaf_3 = leaf;
+	++set.count;
+	uint32_t low;
+	low = (set.leaf_2 < set.leaf_3) ? set.leaf_2 : set.leaf_3; set.leaf_3 = (set.leaf_2 < set.leaf_3) ? set.leaf_3 : set.leaf_2; set.leaf_2 = low;
+	low = (set.leaf_1 < set.leaf_2) ? set.leaf_1 : set.leaf_2; set.leaf_2 = (set.leaf_1 < set.leaf_2) ? set.leaf_2 : set.leaf_1; set.leaf_1 = low;
+	low = (set.leaf_0 < set.leaf_1) ? set.leaf_0 : set.leaf_1; set.leaf_1 = (set.leaf_0 < set.leaf_1) ? set.leaf_1 : set.leaf_0; set.leaf_0 = low;
+}
+
+// One axis of a ray's way through the grid over the lights
+struct PtGridAxis {
+	float t_next, t_step; // where the ray enters the next cell along this axis, and the distance between such places
+	uint32_t remaining;   // cells ahead along this axis
+	uint32_t stride;      // what a step adds to the cell's index (wraps around for steps backwards)
+};
+
+// Clips the ray to the slab of the grid along one axis (false: it misses the
+// slab). The grid ends two margins beyond the outermost light, so a ray that
+// rounding lets slip past it meets no light.
+PT_FN bool pt_grid_clip(float origin, float dir, float lo, float hi, float& t_enter, float& t_leave) {
+	if (dir != 0.0f) {
+		float inv = 1.0f / dir;
+		float t_0 = (lo - origin) * inv, t_1 = (hi - origin) * inv;
+		t_enter = fmaxf(t_enter, fminf(t_0, t_1));
+		t_leave = fminf(t_leave, fmaxf(t_0, t_1));
+		return true;
+	}
+	return origin >= lo && origin <= hi;
+}
+
+PT_FN PtGridAxis pt_grid_axis(float origin, float dir, float t_enter, float lo, float cell, float inv_cell, uint32_t dim, uint32_t stride, uint32_t& index) {
+	float position = fmaf(t_enter, dir, origin);
+	float coordinate = fminf(fmaxf(floorf((position - lo) * inv_cell), 0.0f), (float) (dim - 1));
+	uint32_t i = (uint32_t) coordinate;
+	index += i * stride;
+	PtGridAxis axis;
+	const bool forward = dir > 0.0f;
+	axis.remaining = forward ? (dim - 1u - i) : i;
+	axis.stride = forward ? stride : (0u - stride);
+	if (dir != 0.0f) {
+		float inv = 1.0f / dir;
+		axis.t_next = (fmaf(coordinate + (forward ? 1.0f : 0.0f), cell, lo) - origin) * inv;
+		axis.t_step = cell * fabsf(inv);
+	}
+	else {
+		axis.t_next = 3.0e38f;
+		axis.t_step = 0.0f;
+	}
+	return axis;
+}
+
+// A ray's place in the grid over the lights: its cell, the lights of that cell
+// still to be tested, and what the steps to the next cells need
+struct PtGridWalk {
+	PtGridAxis x, y, z;
+	uint32_t cell, entry, entry_end;
+};
+
+// The place where the ray from origin along dir (of any length) enters the
+// grid. A ray that misses the grid gets a place without lights and without
+// cells ahead.
+PT_FN PtGridWalk pt_light_grid_begin(const PtSceneView& scene, v3 origin, v3 dir) {
+	const uint32_t dim_x = scene.light_grid_dim[0], dim_y = scene.light_grid_dim[1], dim_z = scene.light_grid_dim[2];
+	PtGridWalk walk;
+	float t_enter = 0.0f, t_leave = 3.0e38f;
+	bool meets = pt_grid_clip(origin.x, dir.x, scene.light_grid_lo[0], fmaf((float) dim_x, scene.light_grid_cell[0], scene.light_grid_lo[0]), t_enter, t_leave);
+	meets = pt_grid_clip(origin.y, dir.y, scene.light_grid_lo[1], fmaf((float) dim_y, scene.light_grid_cell[1], scene.light_grid_lo[1]), t_enter, t_leave) && meets;
+	meets = pt_grid_clip(origin.z, dir.z, scene.light_grid_lo[2], fmaf((float) dim_z, scene.light_grid_cell[2], scene.light_grid_lo[2]), t_enter, t_leave) && meets;
+	meets = meets && t_enter <= t_leave;
+	// For a ray that misses, t_enter may be anything, NaN included; the cell
+	// found for it exists all the same
+	walk.cell = 0;
+	walk.x = pt_grid_axis(origin.x, dir.x, t_enter, scene.light_grid_lo[0], scene.light_grid_cell[0], scene.light_grid_inv_cell[0], dim_x, 1u, walk.cell);
+	walk.y = pt_grid_axis(origin.y, dir.y, t_enter, scene.light_grid_lo[1], scene.light_grid_cell[1], scene.light_grid_inv_cell[1], dim_y, dim_x, walk.cell);
+	walk.z = pt_grid_axis(origin.z, dir.z, t_enter, scene.light_grid_lo[2], scene.light_grid_cell[2], scene.light_grid_inv_cell[2], dim_z, dim_x * dim_y, walk.cell);
+	walk.entry = scene.light_grid_cells[walk.cell];
+	walk.entry_end = scene.light_grid_cells[walk.cell + 1];
+	if (!meets) {
+		walk.x.remaining = walk.y.remaining = walk.z.remaining = 0u;
+		walk.entry_end = walk.entry;
+	}
+	return walk;
+}
+
+// Adds to the set the leaves of all lights that the rays from origin along
+// dir_0 and along dir_1 meet, found by following the rays through the grid
+// over the lights cell by cell, the second ray after the first. All of it is
+// one loop, and a pass of it tests one light of the current cell, if there is
+// one left, and then moves on if there is none left: the threads of a
+// wavefront, whose rays pass different numbers of cells and lights, thus wait
+// for the longest sum of the two rays' work, not for the longest cell, the
+// longest first ray and the longest second ray one after the other.
+PT_FN void pt_light_grid_collect_2(const PtSceneView& scene, v3 origin, v3 dir_0, v3 dir_1, PtLeafSet& set) {
+	v3 dir = dir_0;
+	bool second = false;
+	PtGridWalk walk = pt_light_grid_begin(scene, origin, dir);
+	// Every pass tests a light or takes a step or ends a ray, and there are at
+	// most 384 steps per ray and 2^26 listed lights; the bound only keeps an
+	// error from hanging the GPU
+	for (uint32_t pass = 0; pass != (1u << 28); ++pass) {
+		if (walk.entry != walk.entry_end) {
+#ifdef PT_GRID_STATS
+			++g_tests;
+#endif
+			if (pt_ray_meets_light(scene.light_grid_lights[walk.entry], origin, dir))
+				pt_leaf_set_insert(set, scene.light_grid_leaves[walk.entry]);
+			++walk.entry;
+		}
+		if (walk.entry == walk.entry_end) {
+			// Into the neighbour across the nearest cell boundary ahead
+			const bool step_x = walk.x.t_next <= walk.y.t_next && walk.x.t_next <= walk.z.t_next;
+			const bool step_y = !step_x && walk.y.t_next <= walk.z.t_next;
+			const bool step_z = !step_x && !step_y;
+			if ((step_x ? walk.x.remaining : (step_y ? walk.y.remaining : walk.z.remaining)) != 0u) {
+#ifdef PT_GRID_STATS
+				++g_steps;
+#endif
+				walk.cell += step_x ? walk.x.stride : (step_y ? walk.y.stride : walk.z.stride);
+				walk.x.t_next += step_x ? walk.x.t_step : 0.0f; walk.x.remaining -= step_x ? 1u : 0u;
+				walk.y.t_next += step_y ? walk.y.t_step : 0.0f; walk.y.remaining -= step_y ? 1u : 0u;
+				walk.z.t_next += step_z ? walk.z.t_step : 0.0f; walk.z.remaining -= step_z ? 1u : 0u;
+				walk.entry = scene.light_grid_cells[walk.cell];
+				walk.entry_end = scene.light_grid_cells[walk.cell + 1];
+			}
+			else if (!second) {
+				second = true;
+				dir = dir_1;
+				walk = pt_light_grid_begin(scene, origin, dir);
+			}
+			else
+				break;
+		}
+	}
+}
+
+PT_FN void pt_lights_density_tree_walk(const PtSceneView& scene, const PtLightTreeSample& sample, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float* out_density_0, float* out_density_1);
+
 // Densities of two directions under pt_sample_lights_tree(): for each, the sum
 // over the lights that a ray along it meets of selection probability times
-// cone density, in leaf order. One depth-first walk serves both rays; a
+// cone density, in leaf order. The lights come from the grid if there is one;
+// more than four of them, or a shading point far outside, go to the walk of
+// the tree.
+PT_FN void pt_lights_density_tree_2(const PtSceneView& scene, const PtLightTreeSample& sample, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float* out_density_0, float* out_density_1) {
+	if (scene.light_grid_cells && (fabsf(shading_pos.x) + fabsf(shading_pos.y)) + fabsf(shading_pos.z) <= scene.light_grid_reach) {
+		PtLeafSet set;
+		set.leaf_0 = set.leaf_1 = set.leaf_2 = set.leaf_3 = 0xffffffffu;
+		set.count = 0;
+		set.overflow = false;
+		pt_light_grid_collect_2(scene, shading_pos, dir_0, dir_1, set);
+		if (!set.overflow) {
+			float density_0 = 0.0f, density_1 = 0.0f;
+			if (set.count > 0) pt_light_leaf_density(scene, sample, set.leaf_0, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+			if (set.count > 1) pt_light_leaf_density(scene, sample, set.leaf_1, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+			if (set.count > 2) pt_light_leaf_density(scene, sample, set.leaf_2, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+			if (set.count > 3) pt_light_leaf_density(scene, sample, set.leaf_3, shading_pos, normal, dir_0, dir_1, density_0, density_1);
+			*out_density_0 = density_0;
+			*out_density_1 = density_1;
+			return;
+		}
+	}
+	pt_lights_density_tree_walk(scene, sample, shading_pos, normal, dir_0, dir_1, out_density_0, out_density_1);
+}
+
+// The same by a walk of the tree. One depth-first walk serves both rays; a
 // subtree is entered when one of the rays meets its box. Both children of a
 // node are looked at together; a right child still to be entered is remembered
 // as one bit per tree level (the node index itself tells the way back).
-PT_FN void pt_lights_density_tree_2(const PtSceneView& scene, const PtLightTreeSample& sample, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float* out_density_0, float* out_density_1) {
+PT_FN void pt_lights_density_tree_walk(const PtSceneView& scene, const PtLightTreeSample& sample, v3 shading_pos, v3 normal, v3 dir_0, v3 dir_1, float* out_density_0, float* out_density_1) {
 	float density_0 = 0.0f, density_1 = 0.0f;
 	PtSlabRay ray_0 = pt_slab_ray(shading_pos, dir_0), ray_1 = pt_slab_ray(shading_pos, dir_1);
 	f32x4 root_center = scene.light_nodes[2], root_half = scene.light_nodes[3];

@@ -39,6 +39,10 @@ def lib():
         _lib.emu_destroy_scene.argtypes = [C.c_void_p]
         _lib.emu_set_lights.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
         _lib.emu_bvh_info.argtypes = [C.c_void_p, C.c_void_p]
+        _lib.emu_light_grid_mismatches.restype = C.c_uint32
+        _lib.emu_light_grid_mismatches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+        _lib.emu_light_grid_info.restype = None
+        _lib.emu_light_grid_info.argtypes = [C.c_void_p, C.c_void_p]
         _lib.emu_lights_density.restype = None
         _lib.emu_lights_density.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         _lib.emu_light_tree_reuse_mismatches.restype = C.c_uint32
@@ -103,9 +107,23 @@ class EmuScene:
         lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 4)
         lib().emu_set_lights(self.handle, _ptr(lights), len(lights))
 
+    def light_grid_mismatches(self, origins, directions):
+        """(rays whose lights found through the grid differ from a loop over all lights, rays that met more than four
+        lights, lights met in total), or None if the lights have no grid."""
+        origins, directions = (np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (origins, directions))
+        overflows, hits = C.c_uint32(0), C.c_uint32(0)
+        mismatches = lib().emu_light_grid_mismatches(self.handle, _ptr(origins), _ptr(directions), len(origins), C.byref(overflows), C.byref(hits))
+        return None if mismatches == 0xffffffff else (int(mismatches), int(overflows.value), int(hits.value))
+
+    def light_grid_info(self):
+        """Cells per axis and entries of the grid over the lights (zeros: none)."""
+        out = np.zeros(4, np.uint32)
+        lib().emu_light_grid_info(self.handle, _ptr(out))
+        return [int(v) for v in out]
+
     def lights_density(self, positions, normals, directions_0, directions_1, mode):
-        """Densities of two directions per vertex under the light tree's sampling; mode 0: by the walk of the tree,
-        1: by a loop over all lights."""
+        """Densities of two directions per vertex under the light tree's sampling; mode 0: through the grid over the
+        lights, 1: by the walk of the tree, 2: by a loop over all lights."""
         arrays = [np.ascontiguousarray(a, np.float32).reshape(-1, 3) for a in (positions, normals, directions_0, directions_1)]
         out = np.zeros((len(arrays[0]), 2), np.float32)
         lib().emu_lights_density(self.handle, *[_ptr(a) for a in arrays], len(arrays[0]), mode, _ptr(out))

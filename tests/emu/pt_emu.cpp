@@ -36,6 +36,7 @@ struct EmuScene {
 	std::vector<float> srgb;
 	std::vector<f32x4> lights;
 	PtLightTree light_tree;
+	PtLightGrid light_grid;
 	std::vector<PtNode> nodes;
 	std::vector<PtTri> tris;
 	uint32_t node_count, depth, max_stack;
@@ -48,6 +49,16 @@ struct EmuScene {
 		v.texture_table = texture_table.data(); v.texture_blob = blob.data(); v.srgb_to_linear = srgb.data();
 		v.lights = lights.data(); v.light_count = (uint32_t) lights.size(); v.emission_material_index = emission_material_index;
 		v.light_nodes = light_tree.nodes.data(); v.tree_lights = light_tree.lights.data(); v.light_leaf_count = light_tree.leaf_count;
+		// PT_EMU_NO_LIGHT_GRID=1: the walk of the light tree instead of the grid, for comparing the two
+		bool use_grid = light_grid.valid && !getenv("PT_EMU_NO_LIGHT_GRID");
+		v.light_grid_cells = use_grid ? light_grid.cells.data() : NULL;
+		v.light_grid_lights = use_grid ? light_grid.lights.data() : NULL;
+		v.light_grid_leaves = use_grid ? light_grid.leaves.data() : NULL;
+		for (int a = 0; a != 3; ++a) {
+			v.light_grid_lo[a] = light_grid.lo[a]; v.light_grid_cell[a] = light_grid.cell[a];
+			v.light_grid_inv_cell[a] = light_grid.inv_cell[a]; v.light_grid_dim[a] = light_grid.dim[a];
+		}
+		v.light_grid_reach = light_grid.reach;
 		return v;
 	}
 };
@@ -302,10 +313,58 @@ void emu_set_lights(EmuScene* s, const float* lights, uint32_t count) {
 	s->lights.resize(count);
 	if (count) memcpy(s->lights.data(), lights, 16 * (size_t) count);
 	pt_build_light_tree(s->light_tree, lights, count);
+	const char* per_cell = getenv("PT_EMU_LIGHTS_PER_CELL");
+	pt_build_light_grid(s->light_grid, s->light_tree, per_cell ? (float) atof(per_cell) : 0.5f);
 }
 
-// The densities of two directions under the light tree's sampling, two ways: 0 by the walk of the tree, 1 by a loop
-// over all leaves in order (the definition)
+// For every ray the leaves of the lights it meets, found through the grid over the lights, against a loop over all
+// lights with the same test. Returns the number of rays for which the two differ (rays that meet more than four
+// lights, which the grid path hands to the walk of the tree, are counted in out_overflows instead), or 0xffffffff
+// if the lights have no grid.
+uint32_t emu_light_grid_mismatches(EmuScene* s, const float* origins, const float* directions, uint32_t count, uint32_t* out_overflows, uint32_t* out_hits) {
+	if (!s->light_grid.valid)
+		return 0xffffffffu;
+	PtSceneView view = s->view();
+	uint32_t mismatches = 0, overflows = 0, hits = 0;
+	for (uint32_t i = 0; i != count; ++i) {
+		v3 origin = mk3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), dir = mk3(directions[3 * i], directions[3 * i + 1], directions[3 * i + 2]);
+		PtLeafSet set;
+		set.leaf_0 = set.leaf_1 = set.leaf_2 = set.leaf_3 = 0xffffffffu;
+		set.count = 0;
+		set.overflow = false;
+		// The same ray twice: the set keeps a leaf once
+		pt_light_grid_collect_2(view, origin, dir, dir, set);
+		std::vector<uint32_t> expected;
+		for (uint32_t j = 0; j != s->light_tree.leaf_count; ++j) {
+			f32x4 l = s->light_tree.lights[j];
+			if (l.w * l.w > 0.0f && pt_ray_meets_light(l, origin, dir))
+				expected.push_back(s->light_tree.leaf_count + j);
+		}
+		hits += (uint32_t) expected.size();
+		if (set.overflow) {
+			++overflows;
+			mismatches += expected.size() <= 4;
+			continue;
+		}
+		uint32_t found[4] = { set.leaf_0, set.leaf_1, set.leaf_2, set.leaf_3 };
+		bool same = expected.size() == set.count;
+		for (uint32_t k = 0; same && k != set.count; ++k)
+			same = found[k] == expected[k];
+		mismatches += !same;
+	}
+	if (out_overflows) *out_overflows = overflows;
+	if (out_hits) *out_hits = hits;
+	return mismatches;
+}
+
+// Cells per axis of the grid over the lights and the number of its entries (zeros: no grid)
+void emu_light_grid_info(EmuScene* s, uint32_t* out) {
+	for (int a = 0; a != 3; ++a) out[a] = s->light_grid.valid ? s->light_grid.dim[a] : 0u;
+	out[3] = s->light_grid.valid ? (uint32_t) s->light_grid.leaves.size() : 0u;
+}
+
+// The densities of two directions under the light tree's sampling, three ways: 0 through the grid over the lights
+// (with its fallbacks), 1 by the walk of the tree, 2 by a loop over all leaves in order (the definition)
 void emu_lights_density(EmuScene* s, const float* positions, const float* normals, const float* directions_0, const float* directions_1, uint32_t count, int mode, float* out_densities) {
 	PtSceneView view = s->view();
 	PtLightTreeSample none;
@@ -317,6 +376,8 @@ void emu_lights_density(EmuScene* s, const float* positions, const float* normal
 		float density_0 = 0.0f, density_1 = 0.0f;
 		if (mode == 0)
 			pt_lights_density_tree_2(view, none, pos, normal, d0, d1, &density_0, &density_1);
+		else if (mode == 1)
+			pt_lights_density_tree_walk(view, none, pos, normal, d0, d1, &density_0, &density_1);
 		else
 			for (uint32_t j = 0; j != s->light_tree.leaf_count; ++j)
 				if (s->light_tree.lights[j].w * s->light_tree.lights[j].w > 0.0f)

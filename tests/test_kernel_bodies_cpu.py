@@ -190,12 +190,13 @@ def test_render_exact_light_tree(light_count):
 
 
 @pytest.mark.parametrize("layout", ["row", "clusters", "giant", "around_the_scene", "flat", "far_apart"])
-def test_light_tree_layouts_against_oracle(layout):
-    """Light sets that stress the walk of the light tree for the densities: a row of spheres that a ray threads (more
-    hits than are gathered before they are worked off), dense clusters, one light larger than the rest of the scene, one
-    light around the whole scene (directions sampled from inside a light are no unit vectors), all lights in a plane,
-    two groups a thousand extents apart. The kernel body's walk, which serves two rays at once, and the oracle's, one
-    ray at a time, agree bit for bit."""
+def test_light_tree_layouts_against_oracle(layout, monkeypatch):
+    """Which lights a ray meets is looked up in a grid over the lights; the walk of the light tree serves what the grid
+    does not. Light sets that stress both: a row of spheres that a ray threads (more hits than the grid path keeps, so
+    the walk takes over per vertex), dense clusters (crowded cells), one light larger than the rest of the scene (listed
+    in many cells), one light around the whole scene (directions sampled from inside a light are no unit vectors), all
+    lights in a plane (one layer of cells), two groups a thousand extents apart (coarse cells). The kernel body with the
+    grid, the kernel body with the walk alone and the oracle's own walk, one ray at a time, agree bit for bit."""
     rng = np.random.default_rng(77)
     if layout == "row":
         lights = np.array([[-4.0 + 0.9 * i, 0.02 * i, 2.0, 0.3] for i in range(10)] + [[0.5, 1.0, 3.0, 0.2]], np.float32)
@@ -217,17 +218,23 @@ def test_light_tree_layouts_against_oracle(layout):
     spec = synthetic.look_at_spec((0.5, 7.0, 0.3), (1.3, 0.0, 0.4))
     constants = oracle.write_constants(spec, 40, 24, scene, lights)
     a, rays_a = o_scene.render(constants, lights, strategy=3, path_length=4, first_frame_index=3, frame_count=2, threads=4, light_sampling=1)
+    assert e_scene.light_grid_info()[3] >= len(lights)
     b, rays_b = e_scene.render(constants, strategy=4, path_length=4, first_frame_index=3, frame_count=2)
-    assert rays_a == rays_b
+    monkeypatch.setenv("PT_EMU_NO_LIGHT_GRID", "1")
+    c, rays_c = e_scene.render(constants, strategy=4, path_length=4, first_frame_index=3, frame_count=2)
+    assert rays_a == rays_b == rays_c
+    assert ((bits(b) == bits(c)) | (np.isnan(b) & np.isnan(c))).all()
     assert ((bits(a) == bits(b)) | (np.isnan(a) & np.isnan(b))).all()
     assert b[..., :3].sum() > 0
 
 
-def test_light_tree_walk_finds_what_a_loop_over_all_lights_finds():
-    """The densities by the walk of the light tree and by a loop over all lights are the same bits, for rays aimed at
-    lights (also tangentially) and anywhere, from among the lights and from up to a thousand times their extent away,
-    with directions of any length: the boxes of the tree allow for the rounding of the test for a ray meeting a light.
-    And the selection probability kept from the descent equals the one recomputed from the root."""
+def test_light_grid_and_tree_walk_find_what_a_loop_over_all_lights_finds():
+    """The grid over the lights returns exactly the lights that pass the test for a ray meeting a light, and the
+    densities through the grid, by the walk of the light tree and by a loop over all lights are the same bits: for rays
+    aimed at lights (also tangentially) and anywhere, along axes and within axis planes, from among the lights and from
+    up to a thousand times their extent away (beyond the grid's reach the walk serves), with directions of any length.
+    Grid and boxes of the tree allow for the rounding of the test. And the selection probability kept from the descent
+    equals the one recomputed from the root."""
     rng = np.random.default_rng(12)
     scene = synthetic.triangle_soup(seed=3, triangle_count=50, material_count=2)
     e_scene = emu.EmuScene(scene)
@@ -239,9 +246,11 @@ def test_light_tree_walk_finds_what_a_loop_over_all_lights_finds():
             "one": np.array([[1.0, 2.0, 3.0, 0.4]], np.float32),
             "big and small": np.concatenate([synthetic.random_lights(6, 100), np.array([[0, 0, 60.0, 30.0], [3, 3, 3, 2.5]], np.float32)]),
             "flat": synthetic.random_lights(7, 200) * np.array([1, 1, 0, 1], np.float32),
-            "tiny": synthetic.random_lights(8, 100, radius=(1e-4, 1e-3))}
+            "tiny": synthetic.random_lights(8, 100, radius=(1e-4, 1e-3)),
+            "many": synthetic.random_lights(9, 5000, radius=(1e-3, 3e-2))}
     for name, lights in sets.items():
         e_scene.set_lights(lights)
+        assert e_scene.light_grid_info()[3] >= len(lights), name
         count = 12000
         for extent in (6.0, 300.0, 5000.0):
             origins = rng.uniform(-extent, extent, (count, 3)).astype(np.float32)
@@ -249,11 +258,16 @@ def test_light_tree_walk_finds_what_a_loop_over_all_lights_finds():
             # Towards a point on or just off the silhouette of a light, or anywhere
             offset = unit(rng.normal(size=(count, 3))) * aimed[:, 3:4] * rng.choice([0.3, 0.999, 1.0, 1.001], (count, 1))
             directions = np.where(rng.uniform(size=(count, 1)) < 0.6, unit(aimed[:, :3] + offset - origins), unit(rng.normal(size=(count, 3))))
+            kind = rng.integers(0, 6, count)
+            directions[kind == 0, 0] = 0
+            directions[kind == 1, 1:] = 0
             directions = (directions * rng.choice([1.0, 1.0, 0.01, 7.0], (count, 1))).astype(np.float32)
+            mismatches, overflows, hits = e_scene.light_grid_mismatches(origins, directions)
+            assert mismatches == 0, (name, extent, mismatches)
             normals = unit(rng.normal(size=(count, 3)))
             others = unit(rng.normal(size=(count, 3)))
-            by_walk, by_loop = (e_scene.lights_density(origins, normals, directions, others, mode) for mode in range(2))
-            assert (bits(by_walk) == bits(by_loop)).all(), (name, extent)
+            by_grid, by_walk, by_loop = (e_scene.lights_density(origins, normals, directions, others, mode) for mode in range(3))
+            assert (bits(by_grid) == bits(by_loop)).all() and (bits(by_walk) == bits(by_loop)).all(), (name, extent)
             assert (by_loop[:, 0] > 0).sum() > count // 20 or name == "tiny", (name, extent)
             assert e_scene.light_tree_reuse_mismatches(origins, normals, rng.uniform(size=(count, 2))) == 0, name
     e_scene.close()

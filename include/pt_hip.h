@@ -107,8 +107,10 @@ int pt_set_lights(pt_scene_t* scene, const float* lights, uint32_t count);
  * path vertex, selection probability proportional to the solid angle. TREE
  * has no counterpart in the reference, which truncates to 32 lights
  * (src/main.c:691-694): one descent through a binary tree over the lights per
- * vertex, for scenes with thousands of lights; the estimate stays unbiased,
- * its noise differs. The default is EXACT; the other strategies ignore it. */
+ * vertex and a lookup of the lights that a sampled direction meets in a grid
+ * over them, for scenes with thousands of lights; the estimate stays
+ * unbiased, its noise differs. The default is EXACT; the other strategies
+ * ignore it. */
 enum { PT_LIGHT_SAMPLING_EXACT = 0, PT_LIGHT_SAMPLING_TREE = 1 };
 int pt_set_light_sampling(pt_scene_t* scene, int light_sampling);
 

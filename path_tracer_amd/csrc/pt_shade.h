@@ -815,14 +815,15 @@ struct PtLightLeaves {
 // about a thousandth of the distance to the light, which no box or grid over
 // the lights could follow; this form is off by a few millionths of the
 // coordinates involved and holds for directions of any length.
-PT_FN bool pt_ray_meets_light(f32x4 light, v3 shading_pos, v3 dir) {
+PT_FN bool pt_ray_meets_light(f32x4 light, v3 shading_pos, v3 dir, float dir_length_2) {
 	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
 	float in_sphere = dot(center_dir, center_dir) - light.w * light.w;
 	float center_dot_dir = dot(center_dir, dir);
 	v3 lever = cross(center_dir, dir);
-	float length_2 = dot(dir, dir);
-	return dot(lever, lever) <= (light.w * light.w) * length_2 && length_2 > 0.0f && in_sphere >= 0.0f && center_dot_dir >= 0.0f;
+	return dot(lever, lever) <= (light.w * light.w) * dir_length_2 && dir_length_2 > 0.0f && in_sphere >= 0.0f && center_dot_dir >= 0.0f;
 }
+
+PT_FN bool pt_ray_meets_light(f32x4 light, v3 shading_pos, v3 dir) { return pt_ray_meets_light(light, shading_pos, dir, dot(dir, dir)); }
 
 // Adds the share of a leaf's light to the densities of the rays that meet the
 // light
@@ -967,6 +968,7 @@ PT_FN PtGridWalk pt_light_grid_begin(const PtSceneView& scene, v3 origin, v3 dir
 // longest first ray and the longest second ray one after the other.
 PT_FN void pt_light_grid_collect_2(const PtSceneView& scene, v3 origin, v3 dir_0, v3 dir_1, PtLeafSet& set) {
 	v3 dir = dir_0;
+	float dir_length_2 = dot(dir, dir);
 	bool second = false;
 	PtGridWalk walk = pt_light_grid_begin(scene, origin, dir);
 	// Every pass tests a light or takes a step or ends a ray, and there are at
@@ -977,7 +979,7 @@ PT_FN void pt_light_grid_collect_2(const PtSceneView& scene, v3 origin, v3 dir_0
 #ifdef PT_GRID_STATS
 			++g_tests;
 #endif
-			if (pt_ray_meets_light(scene.light_grid_lights[walk.entry], origin, dir))
+			if (pt_ray_meets_light(scene.light_grid_lights[walk.entry], origin, dir, dir_length_2))
 				pt_leaf_set_insert(set, scene.light_grid_leaves[walk.entry]);
 			++walk.entry;
 		}
@@ -1000,6 +1002,7 @@ PT_FN void pt_light_grid_collect_2(const PtSceneView& scene, v3 origin, v3 dir_0
 			else if (!second) {
 				second = true;
 				dir = dir_1;
+				dir_length_2 = dot(dir, dir);
 				walk = pt_light_grid_begin(scene, origin, dir);
 			}
 			else

@@ -976,7 +976,7 @@ PT_FN void pt_light_grid_collect_2(const PtSceneView& scene, v3 origin, v3 dir_0
 	// error from hanging the GPU
 	for (uint32_t pass = 0; pass != (1u << 28); ++pass) {
 		if (walk.entry != walk.entry_end) {
-#ifdef PT_GRID_STATS
+#ifdef PT_GRID_STATS // counters of scripts/light_grid_stats.cpp
 			++g_tests;
 #endif
 			if (pt_ray_meets_light(scene.light_grid_lights[walk.entry], origin, dir, dir_length_2))

@@ -86,6 +86,34 @@ def random_lights(seed, count, extent=10.0, radius=(0.1, 0.5)):
     return lights
 
 
+LIGHT_LAYOUTS = ("row", "clusters", "giant", "around_the_scene", "flat", "far_apart")
+
+
+def light_layout(name):
+    """Light sets that stress the lookup of the lights a ray meets: a row of spheres that a ray threads (more hits than
+    the grid path keeps, so the walk of the light tree takes over per vertex), dense clusters (crowded cells), one light
+    larger than the rest of the scene (listed in many cells), one light around the whole scene (directions sampled from
+    inside a light are no unit vectors), all lights in a plane (one layer of cells), two groups a thousand extents
+    apart (coarse cells; shading points beyond the grid's reach)."""
+    rng = np.random.default_rng(77)
+    if name == "row":
+        return np.array([[-4.0 + 0.9 * i, 0.02 * i, 2.0, 0.3] for i in range(10)] + [[0.5, 1.0, 3.0, 0.2]], np.float32)
+    if name == "clusters":
+        centers = rng.uniform(-5, 5, (6, 3))
+        return np.concatenate([np.concatenate([c + rng.normal(scale=0.15, size=(40, 3)), rng.uniform(0.02, 0.1, (40, 1))], axis=1) for c in centers]).astype(np.float32)
+    if name == "giant":
+        return np.concatenate([random_lights(5, 200), np.array([[0, 0, 60.0, 30.0]], np.float32)])
+    if name == "around_the_scene":
+        return np.concatenate([random_lights(5, 200), np.array([[0, 0, 0.0, 30.0]], np.float32)])
+    if name == "flat":
+        lights = random_lights(6, 150)
+        lights[:, 2] = 2.5
+        return lights
+    if name == "far_apart":
+        return np.concatenate([random_lights(7, 60), random_lights(8, 60) + np.array([9000.0, 0, 0, 0], np.float32)])
+    raise ValueError(name)
+
+
 def lit_room(seed=1, light_count=64, extent=12.0, texture_size=16):
     """A floor, two walls and light_count emissive octahedra floating above the floor, each inscribed in a spherical
     light (like the tessellated light spheres of the reference's scenes). Returns the scene and its lights."""

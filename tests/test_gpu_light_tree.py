@@ -63,6 +63,25 @@ def test_light_tree_exact_room_and_replaced_lights():
     g_scene.close()
 
 
+@pytest.mark.parametrize("layout", synthetic.LIGHT_LAYOUTS)
+def test_light_tree_exact_for_light_layouts(layout):
+    """Light sets that stress the grid over the lights and its fallback to the walk of the tree (more than four lights
+    met, crowded cells, a light listed in many cells, shading points inside a light, one layer of cells, shading points
+    beyond the grid's reach): the library and the oracle agree bit for bit."""
+    lights = synthetic.light_layout(layout)
+    scene = synthetic.triangle_soup(seed=31, triangle_count=1200, material_count=3)
+    g_scene = gpu_scene(scene, lights)
+    g_scene.set_light_sampling(hip_api.LIGHT_SAMPLING_TREE)
+    spec = synthetic.look_at_spec((0.5, 7.0, 0.3), (1.3, 0.0, 0.4))
+    constants = oracle.write_constants(spec, 96, 64, scene, lights)
+    got, rays = render(g_scene, constants, scene, 3, 2, 96, 64)
+    expected, expected_rays = oracle.OracleScene(scene).render(constants, lights, strategy=3, path_length=4, first_frame_index=3, frame_count=2, threads=16, light_sampling=1)
+    assert rays == expected_rays
+    assert same(got, expected)
+    assert got[..., :3].sum() > 0
+    g_scene.close()
+
+
 def test_light_sampling_rejects_unknown_mode():
     scene = synthetic.triangle_soup(seed=1, triangle_count=10, material_count=2, texture_size=4)
     g_scene = gpu_scene(scene, np.zeros((0, 4), np.float32))

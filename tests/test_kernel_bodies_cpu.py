@@ -189,29 +189,12 @@ def test_render_exact_light_tree(light_count):
         assert not (bits(a) == bits(c)).all()
 
 
-@pytest.mark.parametrize("layout", ["row", "clusters", "giant", "around_the_scene", "flat", "far_apart"])
+@pytest.mark.parametrize("layout", synthetic.LIGHT_LAYOUTS)
 def test_light_tree_layouts_against_oracle(layout, monkeypatch):
     """Which lights a ray meets is looked up in a grid over the lights; the walk of the light tree serves what the grid
-    does not. Light sets that stress both: a row of spheres that a ray threads (more hits than the grid path keeps, so
-    the walk takes over per vertex), dense clusters (crowded cells), one light larger than the rest of the scene (listed
-    in many cells), one light around the whole scene (directions sampled from inside a light are no unit vectors), all
-    lights in a plane (one layer of cells), two groups a thousand extents apart (coarse cells). The kernel body with the
-    grid, the kernel body with the walk alone and the oracle's own walk, one ray at a time, agree bit for bit."""
-    rng = np.random.default_rng(77)
-    if layout == "row":
-        lights = np.array([[-4.0 + 0.9 * i, 0.02 * i, 2.0, 0.3] for i in range(10)] + [[0.5, 1.0, 3.0, 0.2]], np.float32)
-    elif layout == "clusters":
-        centers = rng.uniform(-5, 5, (6, 3))
-        lights = np.concatenate([np.concatenate([c + rng.normal(scale=0.15, size=(40, 3)), rng.uniform(0.02, 0.1, (40, 1))], axis=1) for c in centers]).astype(np.float32)
-    elif layout == "giant":
-        lights = np.concatenate([synthetic.random_lights(5, 200), np.array([[0, 0, 60.0, 30.0]], np.float32)])
-    elif layout == "around_the_scene":
-        lights = np.concatenate([synthetic.random_lights(5, 200), np.array([[0, 0, 0.0, 30.0]], np.float32)])
-    elif layout == "flat":
-        lights = synthetic.random_lights(6, 150)
-        lights[:, 2] = 2.5
-    else:
-        lights = np.concatenate([synthetic.random_lights(7, 60), synthetic.random_lights(8, 60) + np.array([9000.0, 0, 0, 0], np.float32)])
+    does not. For light sets that stress both (synthetic.light_layout), the kernel body with the grid, the kernel body
+    with the walk alone and the oracle's own walk, one ray at a time, agree bit for bit."""
+    lights = synthetic.light_layout(layout)
     scene = synthetic.triangle_soup(seed=31, triangle_count=1200, material_count=3)
     o_scene, e_scene = oracle.OracleScene(scene), emu.EmuScene(scene)
     e_scene.set_lights(lights)

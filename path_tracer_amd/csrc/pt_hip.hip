@@ -58,6 +58,7 @@ static_assert(sizeof(float) * PT_LIGHT_CACHE_SIZE * PT_SHADE_BLOCK <= 64 * 1024,
 #define PT_SHADE_WAVES 5 // waves per SIMD that the shading kernel is compiled for
 #endif
 #define PT_INVALID 0xffffffffu
+#define PT_EMISSIVE_COUNTS_OFFSET 56 // two 64-bit counts of k_trace_shadow<..., true> among the queue counters (words 56 to 59)
 
 #define PT_CHECK(call) do { hipError_t pt_err_ = (call); if (pt_err_ != hipSuccess) { \
 	printf("HIP error %s at %s:%d (%s).\n", hipGetErrorString(pt_err_), __FILE__, __LINE__, #call); return 1; } } while (0)
@@ -320,6 +321,7 @@ struct PtTraceArgs {
 	PtCacheLayout cache_layout;
 	unsigned long long* visit_counters; // nodes, triangles of extension rays [0], [1] and of shadow rays [2], [3], or NULL
 	uint32_t* error_word; // PT_ERROR_* bits, checked by pt_synchronize()
+	unsigned long long* emissive_counts; // shadow rays traced and shadow rays that ended at a hit that is not emissive (k_trace_shadow<..., true>)
 };
 
 // pathtrace.frag.glsl:365-386 for every path of the batch
@@ -357,7 +359,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 	queue.count = &a.wf.ext_count[a.bounce];
 	queue.fetch = a.fetch;
 	u32x4* hits = a.wf.hit;
-	pt_trace_wave<COUNT_VISITS>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
+	pt_trace_wave<COUNT_VISITS, false>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
 		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters, a.error_word,
 		[&](uint32_t slot, float path_bits, float, const PtHit& hit) {
 			// Triangle indices stay below 2^31, so the front flag rides in the top
@@ -373,7 +375,8 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 }
 
 // trace_ray_emission() of pathtrace.frag.glsl:203-219 and the MIS sum at :338
-template <bool COUNT_VISITS>
+// EMISSIVE_ONLY: with the skipping of pt_trace_wave() (the nodes and triangles must carry the marks for it)
+template <bool COUNT_VISITS, bool EMISSIVE_ONLY>
 __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_trace_shadow(PtTraceArgs a) {
 	__shared__ PtTraceLds lds;
 	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
@@ -382,7 +385,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 	queue.direction = a.wf.sh_d;
 	queue.count = &a.wf.shadow_count[a.bounce];
 	queue.fetch = a.fetch;
-	pt_trace_wave<COUNT_VISITS>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
+	pt_trace_wave<COUNT_VISITS, EMISSIVE_ONLY>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
 		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters ? a.visit_counters + 2 : NULL, a.error_word,
 		[&](uint32_t slot, float path_bits, float factor, const PtHit& hit) {
 			const PtConstants& c = *a.constants;
@@ -404,7 +407,38 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 				v3 sum = mk3(radiance.x, radiance.y, radiance.z) + term;
 				a.wf.radiance[path] = mk4(sum.x, sum.y, sum.z, 0.0f);
 			}
-		});
+		}, a.emissive_counts);
+}
+
+// The marks that shadow rays read (pt_trace_wave<..., EMISSIVE_ONLY = true>): a
+// triangle's first padding word says whether its material is the emission
+// material ...
+__global__ void __launch_bounds__(PT_BLOCK) k_mark_emissive_triangles(PtTri* tris, uint32_t triangle_count, const uint8_t* materials, uint32_t emission_material_index) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i < triangle_count)
+		tris[i].pad[0] = (materials[tris[i].prim] == emission_material_index) ? 1u : 0u;
+}
+
+// ... and bit i of a node's first padding byte whether such a triangle lies
+// below child i. One launch with inner_children == 0 looks at the triangles
+// among the children only; every further launch carries the marks one level
+// up, so as many of them as the tree has levels complete them. (A launch may
+// see the mark of a child node from before or after that node's thread wrote
+// it: marks only ever gain bits towards their final value.)
+__global__ void __launch_bounds__(PT_BLOCK) k_mark_emissive_nodes(PtNode* nodes, uint32_t node_count, const PtTri* tris, int inner_children) {
+	uint32_t n = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (n >= node_count)
+		return;
+	const uint32_t imask = nodes[n].imask, leafmask = nodes[n].leafmask, child_base = nodes[n].child_base, tri_base = nodes[n].tri_base;
+	uint32_t marks = 0;
+	for (uint32_t slot = 0; slot != 8; ++slot) {
+		const uint32_t below = (1u << slot) - 1u;
+		if (leafmask & (1u << slot))
+			marks |= (tris[tri_base + (uint32_t) __builtin_popcount(leafmask & below)].pad[0] != 0u) ? (1u << slot) : 0u;
+		else if (inner_children && (imask & (1u << slot)))
+			marks |= (((const volatile uint8_t*) nodes[child_base + (uint32_t) __builtin_popcount(imask & below)].pad)[0] != 0) ? (1u << slot) : 0u;
+	}
+	nodes[n].pad[0] = (uint8_t) marks;
 }
 
 // Decodes one mip level (2^log_w texels wide) of a BC1 / BC5 texture into tiled 8-bit texels (pt_load_texel() reads them)
@@ -616,7 +650,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 	queue.direction = a.directions;
 	queue.count = a.count;
 	queue.fetch = a.fetch;
-	pt_trace_wave<false>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
+	pt_trace_wave<false, false>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
 		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, NULL, a.error_word,
 		[&](uint32_t slot, float, float, const PtHit& hit) {
 			a.triangles[slot] = (int32_t) hit.prim;
@@ -716,6 +750,14 @@ struct pt_scene {
 	// settings
 	int strategy;
 	uint32_t path_length, emission_material_index;
+	bool emissive_marks_valid; // nodes and triangles carry the marks for emission_marks_index
+	// Whether shadow rays skip what cannot change their answer: 0 not decided
+	// yet (they do, and count how many of them end blocked; the counts of the
+	// first batch decide), 1 yes, 2 no. emissive_skipping_fixed: set by
+	// PT_SHADOW_SKIPPING, never decided anew
+	int emissive_skipping;
+	bool emissive_skipping_fixed;
+	uint32_t emissive_marks_index;
 	// render targets and wavefront buffers
 	uint32_t width, height;
 	PtBatch frame_layout; // tiles and paths per frame
@@ -747,7 +789,8 @@ struct pt_scene {
 	std::vector<hipEvent_t> event_pool;
 	// queue size snapshots of finished batches and the number of padding
 	// paths (outside the image) that each of them carried in its first queue
-	struct counter_read { uint32_t* counters; uint32_t padding_paths; };
+	struct counter_read { uint32_t* counters; uint32_t padding_paths; uint32_t emissive_marks_serial; };
+	uint32_t emissive_marks_serial; // counts the times the marks were made: the counts of a batch traced with older marks decide nothing
 	std::vector<counter_read> pending_counter_reads;
 	std::vector<uint32_t*> snapshot_pool; // pinned buffers of PT_COUNTER_WORDS words, reused
 };
@@ -861,6 +904,17 @@ static void pt_collect(pt_scene* s) {
 		for (uint32_t k = 0; k <= PT_MAX_PATH_LENGTH; ++k) {
 			s->stats.extension_rays += c[k];
 			s->stats.shadow_rays += c[PT_SHADOW_COUNT_OFFSET + k];
+		}
+		// The first batch that says enough about the shadow rays of this scene
+		// decides whether they go on skipping: yes if a quarter of them are blocked
+		unsigned long long traced = 0, blocked = 0;
+		memcpy(&traced, &c[PT_EMISSIVE_COUNTS_OFFSET], sizeof(traced));
+		memcpy(&blocked, &c[PT_EMISSIVE_COUNTS_OFFSET + 2], sizeof(blocked));
+		if (s->emissive_skipping == 0 && s->pending_counter_reads[i].emissive_marks_serial == s->emissive_marks_serial && traced >= 4096) {
+			s->emissive_skipping = (4 * blocked >= traced) ? 1 : 2;
+			if (getenv("PT_TRACE_DIAGNOSTICS"))
+				printf("trace diagnostics (shadow): %.1f%% of %llu rays ended at a hit that is not emissive; skipping %s\n",
+					100.0 * (double) blocked / (double) traced, traced, (s->emissive_skipping == 1) ? "stays on" : "is turned off");
 		}
 		s->snapshot_pool.push_back(c);
 	}
@@ -1053,6 +1107,7 @@ static int pt_build_bvh(pt_scene* s, const pt_scene_header_t* header) {
 			break;
 		s->bvh_info.node_count = level_end;
 		s->bvh_info.depth = depth;
+		s->emissive_marks_valid = false;
 		result = 0;
 	} while (0);
 	hipEventRecord(end, s->stream);
@@ -1163,6 +1218,14 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 	s->strategy = PT_STRATEGY_NEE;
 	s->path_length = 4;
 	s->emission_material_index = 0;
+	s->emissive_marks_valid = false;
+	s->emissive_marks_index = 0;
+	s->emissive_marks_serial = 0;
+	// PT_SHADOW_SKIPPING=0 or 1 fixes what is otherwise decided by the rays
+	// traced so far (a knob for measurements; the images do not depend on it)
+	const char* skipping = getenv("PT_SHADOW_SKIPPING");
+	s->emissive_skipping_fixed = skipping && (skipping[0] == '0' || skipping[0] == '1');
+	s->emissive_skipping = s->emissive_skipping_fixed ? ((skipping[0] == '1') ? 1 : 2) : 0;
 	s->width = s->height = 0;
 	memset(&s->frame_layout, 0, sizeof(s->frame_layout));
 	s->max_frames_per_batch = 0;
@@ -1356,6 +1419,7 @@ static int pt_set_lights_impl(pt_scene_t* s, const float* lights, uint32_t count
 		hipFree(fresh); hipFree(fresh_nodes); hipFree(fresh_tree_lights); hipFree(fresh_cells); hipFree(fresh_grid_lights); hipFree(fresh_grid_leaves);
 		return 1;
 	}
+	s->emissive_marks_valid = false; // other lights, other shadow rays: the counts behind the skipping start anew
 	hipFree(s->lights); hipFree(s->light_nodes); hipFree(s->tree_lights); hipFree(s->light_grid_cells); hipFree(s->light_grid_lights); hipFree(s->light_grid_leaves);
 	s->light_grid_cells = fresh_cells;
 	s->light_grid_lights = fresh_grid_lights;
@@ -1454,6 +1518,7 @@ static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity, 
 	a.fetch = s->counters + PT_COUNTER_WORDS + 8 * PT_FETCH_STRIDE * (shadow ? PT_SHADOW_COUNT_OFFSET + bounce : bounce);
 	a.visit_counters = s->visit_counters_enabled ? s->visit_counters : NULL;
 	a.error_word = s->error_word;
+	a.emissive_counts = (unsigned long long*) (s->counters + PT_EMISSIVE_COUNTS_OFFSET);
 	return a;
 }
 
@@ -1479,6 +1544,20 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 	{
 		pt_launch_timer timer(s, PT_K_RAYGEN);
 		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count, s->path_length ? path_count : 0u);
+	}
+	if (s->strategy == PT_STRATEGY_NEE && s->path_length > 1 && s->bvh_info.triangle_count != 0
+		&& (!s->emissive_marks_valid || s->emissive_marks_index != s->emission_material_index)) {
+		// The shadow rays' marks for the emission material of these settings
+		hipLaunchKernelGGL(k_mark_emissive_triangles, dim3(pt_grid(s->bvh_info.triangle_count)), dim3(PT_BLOCK), 0, s->stream,
+			s->tris, s->bvh_info.triangle_count, s->materials, s->emission_material_index);
+		for (uint32_t level = 0; level <= s->bvh_info.depth; ++level)
+			hipLaunchKernelGGL(k_mark_emissive_nodes, dim3(pt_grid(s->bvh_info.node_count)), dim3(PT_BLOCK), 0, s->stream,
+				s->nodes, s->bvh_info.node_count, s->tris, level != 0);
+		if (!s->emissive_skipping_fixed)
+			s->emissive_skipping = 0;
+		s->emissive_marks_valid = true;
+		s->emissive_marks_index = s->emission_material_index;
+		++s->emissive_marks_serial;
 	}
 	uint32_t parity = 0;
 	// Short queues get one traversal workgroup per CU, so the shadow rays of a
@@ -1529,10 +1608,15 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 			{
 				pt_launch_timer timer(s, PT_K_TRACE_SHADOW, shadow_stream);
 				PtTraceArgs a = pt_trace_args(s, k, 0, true);
-				if (s->visit_counters_enabled)
-					hipLaunchKernelGGL(k_trace_shadow<true>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, shadow_stream, a);
+				const bool skipping = s->emissive_skipping != 2 && s->emissive_marks_valid;
+				if (s->visit_counters_enabled && skipping)
+					hipLaunchKernelGGL((k_trace_shadow<true, true>), dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, shadow_stream, a);
+				else if (s->visit_counters_enabled)
+					hipLaunchKernelGGL((k_trace_shadow<true, false>), dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, shadow_stream, a);
+				else if (skipping)
+					hipLaunchKernelGGL((k_trace_shadow<false, true>), dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, shadow_stream, a);
 				else
-					hipLaunchKernelGGL(k_trace_shadow<false>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, shadow_stream, a);
+					hipLaunchKernelGGL((k_trace_shadow<false, false>), dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, shadow_stream, a);
 			}
 			if (overlap) {
 				PT_CHECK(hipEventRecord(s->shadow_done, shadow_stream));
@@ -1556,7 +1640,7 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 	else
 		PT_CHECK(hipHostMalloc((void**) &snapshot, sizeof(uint32_t) * PT_COUNTER_WORDS, hipHostMallocDefault));
 	PT_CHECK(hipMemcpyAsync(snapshot, s->counters, sizeof(uint32_t) * PT_COUNTER_WORDS, hipMemcpyDeviceToHost, s->stream));
-	pt_scene::counter_read read = { snapshot, path_count - s->width * s->height * frame_count };
+	pt_scene::counter_read read = { snapshot, path_count - s->width * s->height * frame_count, s->emissive_marks_serial };
 	s->pending_counter_reads.push_back(read);
 	s->stats.paths += (uint64_t) s->width * s->height * frame_count;
 	PT_CHECK(hipGetLastError());

@@ -204,12 +204,34 @@ __device__ __forceinline__ void pt_intersect_triangle_lane(PtHit& hit, const PtL
 
 __device__ __forceinline__ uint32_t pt_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
-// Calls finish(slot, origin_w, direction_w, hit) once per ray of the queue
-template <bool COUNT_VISITS, typename Finish>
+// Calls finish(slot, origin_w, direction_w, hit) once per ray of the queue.
+//
+// EMISSIVE_ONLY is for rays of which nothing is asked but whether the triangle
+// of their closest hit is emissive (trace_ray_emission() of
+// pathtrace.frag.glsl:203-219): hit.prim is then *a* triangle that answers the
+// question like the closest one, or 0xffffffff for no hit. Nodes and triangles
+// carry marks for it (pt_mark_emissive_*: bit i of a node's first padding byte
+// says that an emissive triangle lies below child i, a triangle's first padding
+// word that it is emissive). While the closest hit found so far is not
+// emissive, only something emissive in front of it could change the answer, so
+// children and triangles without the mark are skipped; most rays are blocked
+// by a wall early and then have little left to look at. Should the closest hit
+// turn out emissive after something was skipped, an occluder may have been
+// among the skipped: the ray then walks the tree a second time, up to that
+// hit, and ends at the first triangle in front of it that is not emissive.
+// With 48 % of the shadow rays blocked (generated city) that saves 17 % of the
+// node visits and 12 % of the time; with 12 to 17 % blocked (Cornell box,
+// generated interior) it costs 7 to 10 %.
+template <bool COUNT_VISITS, bool EMISSIVE_ONLY, typename Finish>
 __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache, const PtCacheLayout layout, const PtNode* __restrict__ nodes, const PtTri* __restrict__ tris, uint32_t triangle_count,
 	const PtRayQueue& queue, u32x2* stack_overflow, uint32_t stack_overflow_stride, uint32_t stack_capacity,
-	unsigned long long* visit_counters, uint32_t* error_word, Finish finish)
+	unsigned long long* visit_counters, uint32_t* error_word, Finish finish, unsigned long long* emissive_counts = NULL)
 {
+	// EMISSIVE_ONLY: rays traced, and rays that ended at a hit that is not
+	// emissive, are added to emissive_counts[0] and [1]: the host leaves the
+	// skipping off for scenes in which few rays end so (lights mostly in view:
+	// little to skip, and keeping track of it costs more than it saves)
+	uint32_t finished_count = 0, blocked_count = 0;
 	const uint32_t lane = pt_lane();
 	const uint32_t ray_total = *queue.count;
 	// Eighths of the queue, in multiples of the reservation size
@@ -247,6 +269,9 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	u32x2 ngroup, tgroup;
 	ngroup.x = ngroup.y = tgroup.x = tgroup.y = 0;
 	uint32_t sp = 0;
+	// EMISSIVE_ONLY: bit 0: the closest hit so far is not emissive; bit 1:
+	// something was skipped on that account; bit 2: this is the second walk
+	uint32_t emissive_state = 0;
 	uint32_t node_visits = 0, tri_visits = 0, lds_node_visits = 0, lds_tri_visits = 0;
 	uint32_t pass_count = 0, refill_count = 0, node_pass_count = 0, tri_pass_count = 0;
 	(void) node_pass_count; (void) tri_pass_count;
@@ -305,6 +330,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					direction_w = d.w;
 					active = true;
 					sp = 0;
+					emissive_state = 0;
 					tgroup.x = tgroup.y = 0;
 					hit.prim = 0xffffffffu;
 					hit.t = 1e38f;
@@ -350,6 +376,13 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			node_pass_count += __ballot(active && (tgroup.y & 0xffu) == 0) != 0;
 		// ---- one node per lane that has no triangles pending ----
 		if (active && (tgroup.y & 0xffu) == 0) {
+			if (EMISSIVE_ONLY && (emissive_state & 1u)) {
+				// Of the children still to be entered, only the marked ones (the
+				// second byte holds the marks in the order of the first)
+				uint32_t marked = ngroup.y & ((ngroup.y << 16) | 0x00ffffffu);
+				emissive_state |= (marked != ngroup.y) ? 2u : 0u;
+				ngroup.y = marked;
+			}
 			if (!(ngroup.y & 0xff000000u) && sp != 0) {
 				--sp;
 				pt_vec2 entry;
@@ -359,6 +392,11 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					entry = *(const pt_global_vec2*) &stack_overflow[(uint64_t) (sp - PT_WAVE_STACK) * stack_overflow_stride];
 				ngroup.x = entry.x;
 				ngroup.y = entry.y;
+				if (EMISSIVE_ONLY && (emissive_state & 1u)) {
+					uint32_t marked = ngroup.y & ((ngroup.y << 16) | 0x00ffffffu);
+					emissive_state |= (marked != ngroup.y) ? 2u : 0u;
+					ngroup.y = marked;
+				}
 			}
 			if (ngroup.y & 0xff000000u) {
 				uint32_t bit = 31u - (uint32_t) __builtin_clz(ngroup.y);
@@ -426,17 +464,24 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					missed8 = __builtin_amdgcn_alignbit(missed8, pt_as_uint(tf - tn), 31);
 				}
 				uint32_t hit8 = ~missed8 & 0xffu;
+				if (EMISSIVE_ONLY && (emissive_state & 1u)) {
+					uint32_t marked = hit8 & (w1.z >> 8);
+					emissive_state |= (marked != hit8) ? 2u : 0u;
+					hit8 = marked;
+				}
 				// Inner children: from slot order to visiting order (slot ^ octinv),
 				// three conditional swaps of neighbouring bits, pairs and nibbles
-				uint32_t order = hit8 & imask;
-				uint32_t swap = ((order >> 1) ^ order) & (0x55u & ~neg_x);
+				// (with EMISSIVE_ONLY the marks of those children ride along in the
+				// second byte and end up in the same order)
+				uint32_t order = (hit8 & imask) | (EMISSIVE_ONLY ? (w1.z & (imask << 8)) : 0u);
+				uint32_t swap = ((order >> 1) ^ order) & (0x5555u & ~neg_x);
 				order ^= swap | (swap << 1);
-				swap = ((order >> 2) ^ order) & (0x33u & ~neg_y);
+				swap = ((order >> 2) ^ order) & (0x3333u & ~neg_y);
 				order ^= swap | (swap << 2);
-				swap = ((order >> 4) ^ order) & (0x0fu & ~neg_z);
+				swap = ((order >> 4) ^ order) & (0x0f0fu & ~neg_z);
 				order ^= swap | (swap << 4);
 				ngroup.x = w1.x;
-				ngroup.y = (order << 24) | imask;
+				ngroup.y = (order << 24) | (order & 0xff00u) | imask;
 				// Triangles pending in the low byte (by slot), the leaf mask above
 				// it: a triangle's index is tri_base plus the leaves below its slot
 				tgroup.x = w1.y;
@@ -469,16 +514,47 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				mk3(pt_as_float(t0.x), pt_as_float(t0.y), pt_as_float(t0.z)),
 				mk3(pt_as_float(t0.w), pt_as_float(t1.x), pt_as_float(t1.y)),
 				mk3(pt_as_float(t1.z), pt_as_float(t1.w), pt_as_float(t2.x)), t2.y, tmin);
+			if (EMISSIVE_ONLY && hit.prim == t2.y) {
+				// This triangle is the closest hit now
+				if (t2.z != 0u)
+					emissive_state &= ~1u;
+				else if (emissive_state & 4u) {
+					// Second walk: an occluder in front of the emissive hit answers the question
+					sp = 0;
+					ngroup.y = 0;
+					tgroup.y = 0;
+				}
+				else
+					emissive_state |= 1u;
+			}
 		}
 
 		// ---- retire complete rays ----
+		if (EMISSIVE_ONLY) {
+			const bool ends = active && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0 && emissive_state != 2u;
+			finished_count += (uint32_t) __popcll(__ballot(ends));
+			blocked_count += (uint32_t) __popcll(__ballot(ends && (emissive_state & 1u)));
+		}
 		if (active && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0) {
-			active = false;
-			unfinished = true;
+			if (EMISSIVE_ONLY && emissive_state == 2u) {
+				// Emissive, but not everything in front of it has been looked at
+				emissive_state = 4u;
+				ngroup.x = 0;
+				ngroup.y = 0x80000000u;
+				tgroup.x = tgroup.y = 0;
+			}
+			else {
+				active = false;
+				unfinished = true;
+			}
 		}
 	}
 	if (!drained && lane == 0)
 		atomicOr(error_word, PT_ERROR_PASS_LIMIT);
+	if (EMISSIVE_ONLY && lane == 0) {
+		atomicAdd(&emissive_counts[0], (unsigned long long) finished_count);
+		atomicAdd(&emissive_counts[1], (unsigned long long) blocked_count);
+	}
 	if (COUNT_VISITS) {
 		atomicAdd(&visit_counters[0], (unsigned long long) node_visits);
 		atomicAdd(&visit_counters[1], (unsigned long long) tri_visits);

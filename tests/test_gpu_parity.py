@@ -174,6 +174,37 @@ def test_render_exact_soup_cameras_many_lights(camera_type, soup):
     assert np.nanmax(got[..., :3]) > 0
 
 
+@pytest.mark.parametrize("mode", ["0", "1", None])
+def test_shadow_rays_skip_what_cannot_matter(mode, monkeypatch):
+    """Shadow rays only report whether their closest hit is emissive; while it is not, they skip nodes and triangles
+    without emissive triangles below them, and walk the tree a second time if the closest hit turns out emissive after
+    all. PT_SHADOW_SKIPPING fixes that on or off; otherwise the first batch decides from the share of blocked rays. The
+    image is the oracle's in every case: a room whose lamps are emissive octahedra behind and in front of walls, and a
+    soup in which any triangle may be emissive."""
+    if mode is None:
+        monkeypatch.delenv("PT_SHADOW_SKIPPING", raising=False)
+    else:
+        monkeypatch.setenv("PT_SHADOW_SKIPPING", mode)
+    room, room_lights = synthetic.lit_room(seed=9, light_count=40)
+    soup_scene = synthetic.triangle_soup(seed=77, triangle_count=6000, material_count=3, texture_size=16)
+    for scene, lights, spec in ((room, room_lights, synthetic.look_at_spec((4.0, -5.0, 3.0), (1.15, 0.0, 2.5), sky_strength=0.0)),
+                                (soup_scene, synthetic.random_lights(5, 12), synthetic.look_at_spec((0.5, 7.0, 0.3), (1.3, 0.0, 0.4)))):
+        g_scene = gpu_scene(scene, lights)
+        o_scene = oracle.OracleScene(scene)
+        constants = oracle.write_constants(spec, 128, 72, scene, lights)
+        g_scene.create_render_targets(128, 72)
+        for emission_material in (scene.emission_material_index, 0, 250):
+            g_scene.set_render_settings(3, 4, emission_material)
+            # Two batches: the second one runs with what the first one decided
+            for first in (5, 9):
+                g_scene.render_samples(to_gpu_constants(constants), first, 2, 1, accumulate=False)
+                got, _ = g_scene.read_accumulation()
+                expected, _ = o_scene.render(constants, lights, strategy=3, path_length=4, first_frame_index=first, frame_count=2, threads=16,
+                                             emission_material_index=emission_material)
+                assert same(got, expected), (mode, emission_material, first)
+        g_scene.close()
+
+
 def test_accumulation_semantics(gpu_cornell, cornell, cornell_lights, cornell_spec):
     """Two calls that accumulate equal one call; a call without accumulate restarts (src/main.c:1884-1888)."""
     constants = to_gpu_constants(oracle.write_constants(cornell_spec, 128, 72, cornell, cornell_lights))

@@ -293,6 +293,11 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		if (rays_remain && ((uint32_t) __popcll(idle_mask) >= PT_REFILL_MIN)) {
 			if (COUNT_VISITS)
 				++refill_count;
+			if (EMISSIVE_ONLY) {
+				// A completed ray keeps its state until its lane gets the next ray
+				finished_count += (uint32_t) __popcll(__ballot(unfinished));
+				blocked_count += (uint32_t) __popcll(__ballot(unfinished && (emissive_state & 1u)));
+			}
 			if (unfinished) {
 				finish(slot, origin_w, direction_w, hit);
 				unfinished = false;
@@ -366,6 +371,10 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		}
 		// ---- exit: nothing in flight and nothing left to fetch ----
 		if (!rays_remain && __ballot(active) == 0) {
+			if (EMISSIVE_ONLY) {
+				finished_count += (uint32_t) __popcll(__ballot(unfinished));
+				blocked_count += (uint32_t) __popcll(__ballot(unfinished && (emissive_state & 1u)));
+			}
 			if (unfinished)
 				finish(slot, origin_w, direction_w, hit);
 			drained = true;
@@ -530,11 +539,6 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		}
 
 		// ---- retire complete rays ----
-		if (EMISSIVE_ONLY) {
-			const bool ends = active && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0 && emissive_state != 2u;
-			finished_count += (uint32_t) __popcll(__ballot(ends));
-			blocked_count += (uint32_t) __popcll(__ballot(ends && (emissive_state & 1u)));
-		}
 		if (active && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0) {
 			if (EMISSIVE_ONLY && emissive_state == 2u) {
 				// Emissive, but not everything in front of it has been looked at

@@ -13,15 +13,16 @@ import sys
 summary, workload, target = sys.argv[1:4]
 counters = collections.defaultdict(dict)
 for line in open(summary):
-    parts = line.strip().split(",")
+    parts = line.strip().rsplit(",", 4)  # kernel names with two template arguments contain a comma
     if len(parts) != 5 or parts[0] == "kernel":
         continue
     counters[parts[0]][parts[1]] = float(parts[3])
+    counters[parts[0]]["launches"] = max(counters[parts[0]].get("launches", 0.0), float(parts[2]))
 result = {}
 for kernel, c in counters.items():
     if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
         continue
-    entry = {"fetch_kib_reported": c["FETCH_SIZE"], "write_kib": c["WRITE_SIZE"],
+    entry = {"launches": c["launches"], "fetch_kib_reported": c["FETCH_SIZE"], "write_kib": c["WRITE_SIZE"],
              "hbm_bytes_per_launch": (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0}
     if "SQ_INSTS_VALU" in c and "SQ_THREAD_CYCLES_VALU" in c:
         entry["valu_instructions_per_launch"] = c["SQ_INSTS_VALU"]

@@ -106,11 +106,19 @@ def measured_counters(workload, kernel):
         return None, None
     with open(path) as file:
         entry = json.load(file).get(workload, {})
-    # The shadow kernel has a second template argument (with or without skipping of what cannot matter to the ray,
-    # decided per scene after the first batch): the variant with the most launches is the one of the timed steps
-    variants = [(c.get("launches", 0), name) for name, c in entry.get("kernels", {}).items()
-                if name == kernel or name.startswith(kernel[:-1] + ",")]
-    return (entry["kernels"][max(variants)[1]] if variants else None), entry.get("source")
+    # The traversal kernels have a second template argument (with or without skipping of what cannot matter to the
+    # ray: shadow rays as decided per scene after the first batch, extension rays to the last vertex of a path). The
+    # launches of a step may be of both variants, and the live timing averages over all of them: so do the counters
+    # here, weighted by the launches of each variant.
+    variants = [c for name, c in entry.get("kernels", {}).items() if name == kernel or name.startswith(kernel[:-1] + ",")]
+    if not variants:
+        return None, entry.get("source")
+    launches = sum(c.get("launches", 1.0) for c in variants)
+    merged = {"launches": launches}
+    for key in variants[0]:
+        if key != "launches" and all(key in c for c in variants):
+            merged[key] = sum(c[key] * c.get("launches", 1.0) for c in variants) / launches
+    return merged, entry.get("source")
 
 
 def host_threads(requested=None):

@@ -349,7 +349,10 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtCons
 
 // trace_ray() of pathtrace.frag.glsl:181-199 up to the hit record.
 // Persistent waves: the grid is sized to the chip, not to the queue.
-template <bool COUNT_VISITS>
+// EMISSIVE_ONLY: for the rays to the last vertex of a path, of which shading only wants to know whether they hit
+// something emissive (pathtrace.frag.glsl:323-325); the hit record then names a triangle that answers that like the
+// closest one (see pt_trace_wave())
+template <bool COUNT_VISITS, bool EMISSIVE_ONLY>
 __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_trace_extension(PtTraceArgs a) {
 	__shared__ PtTraceLds lds;
 	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
@@ -359,7 +362,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 	queue.count = &a.wf.ext_count[a.bounce];
 	queue.fetch = a.fetch;
 	u32x4* hits = a.wf.hit;
-	pt_trace_wave<COUNT_VISITS, false>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
+	pt_trace_wave<COUNT_VISITS, EMISSIVE_ONLY>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
 		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters, a.error_word,
 		[&](uint32_t slot, float path_bits, float, const PtHit& hit) {
 			// Triangle indices stay below 2^31, so the front flag rides in the top
@@ -371,7 +374,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 			record.z = pt_as_uint(hit.v);
 			record.w = pt_as_uint(path_bits);
 			hits[slot] = record;
-		});
+		}, a.emissive_counts);
 }
 
 // trace_ray_emission() of pathtrace.frag.glsl:203-219 and the MIS sum at :338
@@ -757,6 +760,7 @@ struct pt_scene {
 	// PT_SHADOW_SKIPPING, never decided anew
 	int emissive_skipping;
 	bool emissive_skipping_fixed;
+	bool emissive_skipping_last_vertex; // the rays to the last vertex of a path skip likewise (off with PT_SHADOW_SKIPPING=0)
 	uint32_t emissive_marks_index;
 	// render targets and wavefront buffers
 	uint32_t width, height;
@@ -1226,6 +1230,7 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 	const char* skipping = getenv("PT_SHADOW_SKIPPING");
 	s->emissive_skipping_fixed = skipping && (skipping[0] == '0' || skipping[0] == '1');
 	s->emissive_skipping = s->emissive_skipping_fixed ? ((skipping[0] == '1') ? 1 : 2) : 0;
+	s->emissive_skipping_last_vertex = !(s->emissive_skipping_fixed && skipping[0] == '0');
 	s->width = s->height = 0;
 	memset(&s->frame_layout, 0, sizeof(s->frame_layout));
 	s->max_frames_per_batch = 0;
@@ -1525,10 +1530,22 @@ static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity, 
 static void pt_launch_trace_extension(pt_scene* s, uint32_t bounce, uint32_t parity, uint32_t capacity) {
 	pt_launch_timer timer(s, PT_K_TRACE_EXT);
 	PtTraceArgs a = pt_trace_args(s, bounce, parity, false);
-	if (s->visit_counters_enabled)
-		hipLaunchKernelGGL(k_trace_extension<true>, dim3(pt_trace_grid(s, capacity)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+	// The rays to the last vertex only ask whether they hit something emissive.
+	// Most of them hit something that is not, so the skipping pays for them
+	// (city: that launch -20 %) unless the whole tree sits in LDS, where a
+	// node costs too little (Cornell box: +2 %); their counts go to words of
+	// their own and decide nothing
+	const bool emissive_only = bounce + 1 == s->path_length && s->emissive_marks_valid && s->emissive_skipping_last_vertex
+		&& a.cache_layout.node_count < s->bvh_info.node_count;
+	a.emissive_counts = (unsigned long long*) (s->counters + PT_EMISSIVE_COUNTS_OFFSET + 4);
+	if (s->visit_counters_enabled && emissive_only)
+		hipLaunchKernelGGL((k_trace_extension<true, true>), dim3(pt_trace_grid(s, capacity)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+	else if (s->visit_counters_enabled)
+		hipLaunchKernelGGL((k_trace_extension<true, false>), dim3(pt_trace_grid(s, capacity)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+	else if (emissive_only)
+		hipLaunchKernelGGL((k_trace_extension<false, true>), dim3(pt_trace_grid(s, capacity)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 	else
-		hipLaunchKernelGGL(k_trace_extension<false>, dim3(pt_trace_grid(s, capacity)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+		hipLaunchKernelGGL((k_trace_extension<false, false>), dim3(pt_trace_grid(s, capacity)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 }
 
 // Renders one batch of frame_count frames
@@ -1545,7 +1562,7 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 		pt_launch_timer timer(s, PT_K_RAYGEN);
 		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count, s->path_length ? path_count : 0u);
 	}
-	if (s->strategy == PT_STRATEGY_NEE && s->path_length > 1 && s->bvh_info.triangle_count != 0
+	if (s->path_length >= 1 && s->bvh_info.triangle_count != 0
 		&& (!s->emissive_marks_valid || s->emissive_marks_index != s->emission_material_index)) {
 		// The shadow rays' marks for the emission material of these settings
 		hipLaunchKernelGGL(k_mark_emissive_triangles, dim3(pt_grid(s->bvh_info.triangle_count)), dim3(PT_BLOCK), 0, s->stream,
@@ -1822,7 +1839,7 @@ static int pt_trace_primary_rays_impl(pt_scene_t* s, const pt_constants_t* const
 			break;
 		hipLaunchKernelGGL(k_raygen, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->constants, s->wf, path_count, path_count);
 		PtTraceArgs a = pt_trace_args(s, 0, 0, false);
-		hipLaunchKernelGGL(k_trace_extension<false>, dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
+		hipLaunchKernelGGL((k_trace_extension<false, false>), dim3(pt_trace_grid(s, path_count)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 		hipLaunchKernelGGL(k_gather_primary_hits, dim3(pt_grid(path_count)), dim3(PT_BLOCK), 0, s->stream, batch, s->wf, d_triangles, d_barycentrics, d_front);
 		if (hipMemcpyAsync(triangle_indices, d_triangles, pixels * sizeof(int32_t), hipMemcpyDeviceToHost, s->stream) != hipSuccess
 			|| hipMemcpyAsync(barycentrics, d_barycentrics, 2 * pixels * sizeof(float), hipMemcpyDeviceToHost, s->stream) != hipSuccess

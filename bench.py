@@ -2,11 +2,15 @@
 
 python bench.py --gpus N --steps K --warmup W
 One step = one pass of the hot path over one batch: --spp-per-step frames of the workload at full resolution.
-For N > 1 the driver launches one process per GPU (torch.distributed, backend "nccl" = RCCL); every rank renders
-its own interleaved slice of frame indices and the accumulation targets are summed with one all-reduce inside the
-timed region (its duration is also reported on its own). --scaling weak (default) fixes the work per GPU
-(--spp-per-step frames per GPU and step), --scaling strong fixes the total (--spp-per-step frames per step shared by
-all GPUs). Rank 0 prints one JSON line.
+Two ways to use N > 1 GPUs, both with the scene replicated, the frame indices shared out in interleaved slices and
+one sum of the accumulation targets over xGMI inside the timed region (its duration is also reported on its own):
+* launched under torch.distributed.run (WORLD_SIZE set): one process per GPU, all-reduce of the "nccl" (= RCCL) backend;
+* launched plainly as `python bench.py --gpus N`: one process drives N GPUs through the library's own multi-GPU
+  entry points (pt_create_context, pt_context_render_samples, pt_context_reduce), as a C host would. With fewer than
+  N GPUs visible it says so and exits with a nonzero code; it never measures fewer GPUs than it was asked for.
+Two legs are timed, and both are in the line: weak scaling (--spp-per-step frames per GPU and step) and strong
+scaling (--strong-frames frames per step shared by all GPUs: the same total whatever N is, at least 32 frames per GPU
+up to eight GPUs). --scaling names the leg that `value` reports (weak by default). Rank 0 prints one JSON line.
 
 The default workload is the configuration the headline metric is quoted on: the Bistro exterior at 1920x1080 with
 the reference's 28 Bistro lights and its bistro/outside.rt_save camera. The Bistro mesh and textures are a separate
@@ -61,7 +65,7 @@ def workload_root(args, rank, barrier=None):
     return root
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=32)
@@ -71,11 +75,14 @@ def parse_args():
     p.add_argument("--spp-per-step", type=int, default=32)
     p.add_argument("--path-length", type=int, default=4)
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--force-collectives", action="store_true", help="take the multi-GPU code path (process group, all-reduce) even with one rank")
+    p.add_argument("--force-collectives", action="store_true", help="take the one-process-per-GPU code path (process group, all-reduce) even with one rank")
+    p.add_argument("--force-context", action="store_true", help="take the one-process-many-GPUs code path (pt_create_context ... pt_context_reduce) even with one GPU")
+    p.add_argument("--strong-frames", type=int, default=256, help="frames per step of the strong-scaling leg, shared by all GPUs (0 skips the leg)")
+    p.add_argument("--strong-steps", type=int, default=None, help="steps of the strong-scaling leg (default: a quarter of --steps, at least 2)")
     p.add_argument("--workload", choices=sorted(WORKLOADS), default="city",
                    help="city: generated stand-in for the Bistro exterior (the metric's configuration); cornell: the reference's own scene file; interior: generated stand-in for Arcade")
     p.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                   help="weak: --spp-per-step frames per GPU and step; strong: --spp-per-step frames per step shared by all GPUs")
+                   help="the leg that `value` reports. weak: --spp-per-step frames per GPU and step; strong: --strong-frames frames per step shared by all GPUs")
     p.add_argument("--cpu-threads", type=int, default=None, help="threads of the CPU baseline (default: the CPUs this process may use)")
     p.add_argument("--triangles", type=int, default=None, help="triangle budget of a generated workload")
     p.add_argument("--texture-size", type=int, default=None, help="edge length of the textures of a generated workload (default 256)")
@@ -84,7 +91,7 @@ def parse_args():
     p.add_argument("--light-sampling", choices=("loop", "tree"), default="loop",
                    help="loop: the reference's loops over all lights per vertex; tree: one descent through the light tree")
     p.add_argument("--scene-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "pt_scenes"))
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
 def trace_bytes_per_ray(kind, nodes_per_ray, tris_per_ray, node_bytes, tri_bytes):
@@ -171,101 +178,226 @@ def cpu_baseline(args, threads, root, first_frame_index):
                       % (label, width, height, spp, args.path_length, rays, best)}
 
 
-def main():
-    args = parse_args()
-    # The C host reports progress on stdout like the reference does; keep stdout for the one JSON line
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
+class Ranks:
+    """One process per GPU: this rank's scene, slices by rank, all-reduce of torch.distributed (RCCL). A single
+    process without a process group is the one-GPU case of the same thing."""
+
+    def __init__(self, args, spec, root, world_size, rank, local_rank, torch=None):
+        from path_tracer_amd import hip_api, host_api
+        self.world_size, self.rank = world_size, rank
+        # torch is plumbing for the process group only; without one it is not even imported
+        self.torch = torch if (torch is not None and torch.distributed.is_initialized()) else None
+        self.distributed = self.torch is not None
+        self.renderer = host_api.Renderer(spec, root, device=local_rank, width=args.width, height=args.height,
+                                          sampling_strategy=hip_api.SAMPLING_STRATEGY_NEE, path_length=args.path_length)
+        self.renderers = [self.renderer]
+        self.gpu_count = world_size
+        self.parallelism = "one process per GPU, sample slices x%d + all-reduce" % world_size if self.distributed else "one GPU"
+
+    def render(self, constants, first_frame_index, frame_count, accumulate):
+        from path_tracer_amd import hip_api, multi_gpu
+        import ctypes as C
+        first, count, stride = multi_gpu.frame_slice(self.rank, self.world_size, first_frame_index, frame_count)
+        if count and hip_api.lib().pt_render_samples(self.renderer.device_scene, C.byref(constants), first, count, stride, int(accumulate)):
+            raise RuntimeError("pt_render_samples failed")
+
+    def barrier(self):
+        self.renderer.synchronize()
+        if self.distributed:
+            self.torch.cuda.synchronize()
+            self.torch.distributed.barrier()
+            self.torch.cuda.synchronize()
+
+    def warm_up_reduction(self):
+        from path_tracer_amd import multi_gpu
+        if self.distributed:
+            self.torch.distributed.all_reduce(multi_gpu.accumulation_tensor(self.renderer))
+
+    def reduce(self, total_sample_count):
+        """Sums the targets of all GPUs; returns the seconds it took."""
+        from path_tracer_amd import multi_gpu
+        self.renderer.synchronize()
+        begin = time.perf_counter()
+        if self.distributed:
+            multi_gpu.all_reduce_accumulation(self.renderer, total_sample_count=total_sample_count)
+        return time.perf_counter() - begin
+
+    def totals(self, rays, paths, seconds, reduce_seconds):
+        """(rays, paths) summed and (seconds, reduce_seconds) maximised over the ranks."""
+        if not self.distributed:
+            return rays, paths, seconds, reduce_seconds
+        dist, torch = self.torch.distributed, self.torch
+        sums = torch.tensor([float(rays), float(paths)], dtype=torch.float64, device="cuda")
+        maxima = torch.tensor([seconds, reduce_seconds], dtype=torch.float64, device="cuda")
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(maxima, op=dist.ReduceOp.MAX)
+        return float(sums[0]), float(sums[1]), float(maxima[0]), float(maxima[1])
+
+    def per_gpu(self, stats_list):
+        return None
+
+    def close(self):
+        self.renderer.close()
+        if self.distributed:
+            self.torch.distributed.destroy_process_group()
+
+
+class Context:
+    """One process, several GPUs through the C ABI: pt_create_context, pt_context_render_samples, pt_context_reduce."""
+
+    def __init__(self, args, spec, root, devices):
+        from path_tracer_amd import hip_api, host_api
+        self.lib = hip_api.lib()
+        self.renderer = host_api.Renderer(spec, root, width=args.width, height=args.height, devices=list(devices),
+                                          sampling_strategy=hip_api.SAMPLING_STRATEGY_NEE, path_length=args.path_length)
+        self.context = self.renderer.device_context
+        self.gpu_count = int(self.lib.pt_context_device_count(self.context))
+        self.devices = list(devices)
+        # A view of every replica for statistics and instrumentation; replica 0 is what the renderer itself shows
+        self.renderers = [self.renderer] + [host_api.ReplicaView(self.renderer, self.lib.pt_context_scene(self.context, i)) for i in range(1, self.gpu_count)]
+        self.rank, self.world_size, self.distributed = 0, 1, False
+        self.parallelism = "one process, %d GPU%s through pt_create_context: sample slices + pt_context_reduce (RCCL reduce over xGMI)" % (self.gpu_count, "" if self.gpu_count == 1 else "s")
+
+    def render(self, constants, first_frame_index, frame_count, accumulate):
+        import ctypes as C
+        if self.lib.pt_context_render_samples(self.context, C.byref(constants), first_frame_index, frame_count, int(accumulate)):
+            raise RuntimeError("pt_context_render_samples failed")
+
+    def barrier(self):
+        self.renderer.synchronize()
+
+    def warm_up_reduction(self):
+        self.renderer.reduce()
+
+    def reduce(self, total_sample_count):
+        self.renderer.reduce()
+        return self.lib.pt_context_last_reduce_ms(self.context) * 1e-3
+
+    def totals(self, rays, paths, seconds, reduce_seconds):
+        return rays, paths, seconds, reduce_seconds
+
+    def per_gpu(self, stats_list):
+        return [{"device": d, "extension_rays": int(s.extension_rays), "shadow_rays": int(s.shadow_rays), "paths": int(s.paths)} for d, s in zip(self.devices, stats_list)]
+
+    def close(self):
+        self.renderer.close()
+
+
+def timed_leg(backend, constants, next_frame, frames_per_step, steps, warmup, kernel_timing):
+    """warmup untimed steps, then exactly `steps` steps and the sum of the targets between two barriers.
+    Returns rays, paths (all GPUs), seconds and reduction seconds (maximum over ranks), and every replica's statistics."""
+    def step(accumulate):
+        backend.render(constants, next_frame[0], frames_per_step, accumulate)
+        next_frame[0] += frames_per_step
+
+    for _ in range(warmup):
+        step(True)
+    backend.warm_up_reduction()
+    for r in backend.renderers:
+        r.set_instrumentation(kernel_timing=kernel_timing, visit_counters=False)
+        r.reset_statistics()
+    backend.barrier()
+    begin = time.perf_counter()
+    for i in range(steps):
+        step(i != 0)
+    reduce_seconds = backend.reduce(steps * frames_per_step)
+    backend.barrier()
+    seconds = time.perf_counter() - begin
+    stats_list = [r.statistics() for r in backend.renderers]
+    rays = sum(s.extension_rays + s.shadow_rays for s in stats_list)
+    paths = sum(s.paths for s in stats_list)
+    rays, paths, seconds, reduce_seconds = backend.totals(rays, paths, seconds, reduce_seconds)
+    return {"rays": rays, "paths": paths, "seconds": seconds, "reduce_seconds": reduce_seconds, "stats": stats_list,
+            "frames_per_step": frames_per_step, "steps": steps}
+
+
+def leg_summary(leg, gpu_count):
+    return {"value": leg["rays"] / leg["seconds"] * 1e-6, "unit": "Mrays/s", "samples_per_s": leg["paths"] / leg["seconds"], "steps": leg["steps"],
+            "first_frame_index": leg["first_frame_index"], "frames_per_step": leg["frames_per_step"], "frames_per_gpu_and_step": leg["frames_per_step"] / gpu_count,
+            "ms_per_step": leg["seconds"] / leg["steps"] * 1e3, "all_reduce_ms": leg["reduce_seconds"] * 1e3}
+
+
+def run(args, image_out=None):
+    """The benchmark proper; returns the result (rank 0) or None. image_out: a list that receives the summed
+    accumulation target of the leg that `value` reports and its sample count (for tests)."""
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch
-    import torch.distributed as dist
-    from path_tracer_amd import hip_api, host_api, multi_gpu
-
-    if not torch.cuda.is_available():
+    from path_tracer_amd import hip_api, host_api
+    import ctypes as C
+    lib = hip_api.lib()
+    under_launcher = ("WORLD_SIZE" in os.environ and "RANK" in os.environ) or args.force_collectives
+    use_context = not under_launcher and (args.gpus > 1 or args.force_context)
+    visible = int(lib.pt_get_device_count())
+    if visible == 0:
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    distributed = world_size > 1 or args.force_collectives
-    if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
-
-    root = workload_root(args, rank, dist.barrier if distributed else None)
+    if under_launcher and world_size != args.gpus and not args.force_collectives:
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree" % (args.gpus, world_size))
+    if use_context and visible < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU%s visible to this process; refusing to measure fewer GPUs than asked for" % (args.gpus, visible, " is" if visible == 1 else "s are"))
+    torch = None
+    if under_launcher:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        if world_size > 1 or args.force_collectives:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+    root = workload_root(args, rank, torch.distributed.barrier if (torch is not None and torch.distributed.is_initialized()) else None)
     name, _, save, label, _ = WORKLOADS[args.workload]
     spec = host_api.quickload(os.path.join(root, "data", "saves", save))
-    renderer = host_api.Renderer(spec, root, device=local_rank, width=args.width, height=args.height,
-                                 sampling_strategy=hip_api.SAMPLING_STRATEGY_NEE, path_length=args.path_length)
+
+    # The CPU legs come first, so that the GPU phase below is one contiguous stretch at the end of the run
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world_size == 1 and not use_context:
+        cpu = cpu_baseline(args, host_threads(args.cpu_threads), root, spec.frame_index + 1)
+
+    backend = Context(args, spec, root, range(args.gpus)) if use_context else Ranks(args, spec, root, world_size, rank, local_rank, torch)
+    gpu_count = backend.gpu_count
+    renderer = backend.renderer
     constants = renderer.constants()
-    lib = hip_api.lib()
-    import ctypes as C
     light_count = renderer.lit_scene.spherical_light_count
     if args.lights is not None:
         header = renderer.lit_scene.scene.header
         lights = generated_lights(args.lights, list(header.dequantization_factor), list(header.dequantization_summand))
-        if lib.pt_set_lights(renderer.device_scene, lights.ctypes.data_as(C.c_void_p), len(lights)):
+        set_lights = (lambda: lib.pt_context_set_lights(backend.context, lights.ctypes.data_as(C.c_void_p), len(lights))) if use_context \
+            else (lambda: lib.pt_set_lights(renderer.device_scene, lights.ctypes.data_as(C.c_void_p), len(lights)))
+        if set_lights():
             raise RuntimeError("pt_set_lights failed")
         light_count = len(lights)
     renderer.set_light_sampling(hip_api.LIGHT_SAMPLING_TREE if args.light_sampling == "tree" else hip_api.LIGHT_SAMPLING_EXACT)
 
     spp = args.spp_per_step
     next_frame = [spec.frame_index + 1]
-
-    # Frames per step over all GPUs: fixed per GPU (weak) or fixed in total (strong)
-    frames_per_step = spp * world_size if args.scaling == "weak" else spp
-
-    def render_step(accumulate):
-        # Sample slices: rank r renders frames base + r, base + r + G, ...
-        first, count, stride = multi_gpu.frame_slice(rank, world_size, next_frame[0], frames_per_step)
-        if count:
-            code = lib.pt_render_samples(renderer.device_scene, C.byref(constants), first, count, stride, int(accumulate))
-            if code:
-                raise RuntimeError("pt_render_samples failed")
-        next_frame[0] += frames_per_step
-
-    def barrier():
-        renderer.synchronize()
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     # One instrumented step for the per-ray node and triangle counts (deterministic given the frame indices)
     renderer.set_instrumentation(kernel_timing=False, visit_counters=True)
     renderer.reset_statistics()
-    render_step(False)
-    renderer.synchronize()
+    backend.render(constants, next_frame[0], spp * gpu_count, False)
+    next_frame[0] += spp * gpu_count
+    backend.barrier()
     profile = renderer.statistics()
     renderer.set_instrumentation(kernel_timing=False, visit_counters=False)
-    for _ in range(args.warmup):
-        render_step(True)
-    tensor = multi_gpu.accumulation_tensor(renderer)
-    if distributed:
-        dist.all_reduce(tensor)  # warm up the communicator
-    renderer.set_instrumentation(kernel_timing=True, visit_counters=False)
-    renderer.reset_statistics()
-    barrier()
-    begin = time.perf_counter()
-    for step in range(args.steps):
-        render_step(step != 0)
-    renderer.synchronize()
-    reduce_begin = time.perf_counter()
-    multi_gpu.all_reduce_accumulation(renderer, total_sample_count=args.steps * frames_per_step)
-    all_reduce_seconds = time.perf_counter() - reduce_begin
-    barrier()
-    seconds = time.perf_counter() - begin
-    stats = renderer.statistics()
-    rays = stats.extension_rays + stats.shadow_rays
-    totals = torch.tensor([float(rays), float(stats.paths), seconds, all_reduce_seconds], dtype=torch.float64, device="cuda")
-    if distributed:
-        maximum = totals.clone()
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
-        dist.all_reduce(maximum, op=dist.ReduceOp.MAX)
-        seconds = float(maximum[2])
-        all_reduce_seconds = float(maximum[3])
-    total_rays, total_paths = float(totals[0]), float(totals[1])
 
+    plans = [("weak", spp * gpu_count, args.steps, args.warmup)]
+    if args.strong_frames > 0:
+        strong_steps = args.strong_steps or (args.steps if args.scaling == "strong" else max(2, args.steps // 4))
+        plans.append(("strong", args.strong_frames, strong_steps, min(args.warmup, 1)))
+    elif args.scaling == "strong":
+        raise SystemExit("--scaling strong needs --strong-frames > 0")
+    legs = {}
+    for leg_name, frames_per_step, steps, warmup in plans:
+        first_timed_frame = next_frame[0] + warmup * frames_per_step
+        legs[leg_name] = timed_leg(backend, constants, next_frame, frames_per_step, steps, warmup, kernel_timing=leg_name == args.scaling)
+        legs[leg_name]["first_frame_index"] = first_timed_frame
+        if leg_name == args.scaling and image_out is not None:
+            image_out.extend(renderer.read_accumulation())
+    main_leg = legs[args.scaling]
+    stats = main_leg["stats"][0]
+    seconds = main_leg["seconds"]
+    total_rays, total_paths = main_leg["rays"], main_leg["paths"]
+
+    result = None
     if rank == 0:
         info = renderer.bvh_info()
         kinds = (("extension", 1, profile.extension_rays, 0), ("shadow", 2, profile.shadow_rays, 1))
@@ -286,7 +418,7 @@ def main():
         d = kernels[dominant]
         # Counters exist for the configurations that were profiled: the default batch of the workloads as they are
         profiled = spp == 32 and not args.triangles and args.lights is None and not args.texture_size and args.light_sampling == "loop" \
-            and (args.width, args.height, args.path_length) == (1920, 1080, 4) and world_size == 1
+            and (args.width, args.height, args.path_length) == (1920, 1080, 4) and args.scaling == "weak"
         counters, counter_source = measured_counters(args.workload, "k_trace_%s<false>" % dominant) if profiled else (None, None)
         # What bounds the kernel, from what the hardware counted rather than from the byte model: the HBM traffic
         # of a launch against the 8 TB/s of the part, and the VALU wave instructions of a launch against what the
@@ -322,35 +454,52 @@ def main():
             "address_unit_stalled_by_l1_frac": counters.get("address_unit_stalled_by_l1_frac") if counters else None,
             "l2_read_latency_cycles": counters.get("l2_read_latency_cycles") if counters else None,
             "l1_read_requests_per_cycle_and_cu": counters.get("l1_read_requests_per_cycle_and_cu") if counters else None,
+            # The same kernel's average duration in the kernel trace that was taken on the box of the counter passes:
+            # set against avg_launch_ms (this run, this box) it shows how far the two runs are apart
+            "counter_run_ms": counters.get("kernel_trace_avg_ms") if counters else None,
             "avg_launch_ms": d["avg_ms"], "rays_per_launch": d["rays_per_launch"],
             "algorithmic_bytes_per_launch": d["bytes_per_ray"] * d["rays_per_launch"], "algorithmic_gbs": d["achieved_gbs"],
             "bytes_per_ray": d["bytes_per_ray"], "nodes_per_ray": d["nodes_per_ray"], "triangles_per_ray": d["tris_per_ray"]})
+        summaries = {name: leg_summary(leg, gpu_count) for name, leg in legs.items()}
         result = {
             "metric": "Mrays/s", "value": total_rays / seconds * 1e-6, "unit": "Mrays/s",
-            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup, "ms_per_step": seconds / args.steps * 1e3,
+            "n_gpus": gpu_count, "steps": main_leg["steps"], "warmup": args.warmup, "ms_per_step": seconds / main_leg["steps"] * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
             "data": ("Cornell box scene file of the reference (fixture copy of data/cornell_box.vks, its textures, lights and quicksave)" if args.workload == "cornell"
                      else "synthetic: scene generated by path_tracer_amd/tools/procedural.py in the reference's file formats (the reference's Bistro assets are not available)"),
-            "config": {"workload": "%s %dx%d, NEE + MIS, path length %d, %d spp per step %s, frames %d.." % (label, args.width, args.height, args.path_length, spp, "per GPU" if args.scaling == "weak" else "over all GPUs", spec.frame_index + 1),
+            "config": {"workload": "%s %dx%d, NEE + MIS, path length %d, %d frames per step (%s), frames %d.." % (
+                           label, args.width, args.height, args.path_length, main_leg["frames_per_step"],
+                           "%d per GPU" % spp if args.scaling == "weak" else "shared by all GPUs", spec.frame_index + 1),
                        "lights": int(light_count), "light_sampling": args.light_sampling,
-                       "spp_total": args.steps * frames_per_step, "parallelism": "sample slices x%d + all-reduce" % world_size},
+                       "spp_total": main_leg["steps"] * main_leg["frames_per_step"], "parallelism": backend.parallelism},
             "samples_per_s": total_paths / seconds,
             "rays_per_path": total_rays / total_paths,
-            "all_reduce_ms": all_reduce_seconds * 1e3,
+            "all_reduce_ms": main_leg["reduce_seconds"] * 1e3,
+            "weak": summaries.get("weak"), "strong": summaries.get("strong"),
+            "per_gpu": backend.per_gpu(main_leg["stats"]),
             "roofline": roofline,
             "kernel_ms": {name: stats.kernel_ms[i] for i, name in enumerate(hip_api.KERNEL_NAMES)},
             "traversal": {name: {"nodes_per_ray": k["nodes_per_ray"], "triangles_per_ray": k["tris_per_ray"], "avg_launch_ms": k["avg_ms"]} for name, k in kernels.items()},
+            "shadow_skipping": {"state": ("undecided", "on", "off")[stats.shadow_skipping], "fixed_by_environment": bool(stats.shadow_skipping_fixed),
+                                "decided_on_rays": int(stats.shadow_rays_decided_on),
+                                "blocked_share": (stats.shadow_rays_blocked / stats.shadow_rays_decided_on) if stats.shadow_rays_decided_on else None},
             "bvh": {"nodes": info.node_count, "triangles": info.triangle_count, "depth": info.depth, "build_ms": info.build_ms},
+            "cpu_baseline": cpu,
         }
-        if not args.no_cpu_baseline and world_size == 1:
-            result["cpu_baseline"] = cpu_baseline(args, host_threads(args.cpu_threads), root, spec.frame_index + 1)
-        else:
-            result["cpu_baseline"] = None
+    backend.close()
+    return result
+
+
+def main():
+    args = parse_args()
+    # The C host reports progress on stdout like the reference does; keep stdout for the one JSON line
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    result = run(args)
+    if result is not None:
+        import ctypes as C
         C.CDLL(None).fflush(None)
         os.write(json_fd, (json.dumps(result) + "\n").encode())
-    renderer.close()
-    if distributed:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -20,6 +20,19 @@
 extern "C" {
 #endif
 
+/* Counts changes of this header that a caller built against an older one
+ * would not survive (arguments inserted, structures that grew). A binding
+ * compares its own copy with pt_abi_version() of the library it loaded and
+ * refuses to go on when they differ. No counterpart in the reference, whose
+ * host and shaders are built together. */
+#define PT_HIP_ABI_VERSION 3u
+uint32_t pt_abi_version(void);
+
+/* The number of GPUs that device_index / device_ids may name (0 when there
+ * is none or the HIP runtime fails). Replaces the enumeration of physical
+ * devices in create_device() at src/vulkan_basics.c:43-68. */
+uint32_t pt_get_device_count(void);
+
 /* The uniform block that the reference uploads once per frame:
  * constants_t at src/main.h:237-256 = src/shaders/constants.glsl:1-39
  * (784 bytes, std140, row_major matrices). frame_index and
@@ -190,6 +203,11 @@ int pt_context_synchronize(pt_context_t* context);
  * reduction took (sum, alpha, clears), for throughput reports. */
 int pt_context_reduce(pt_context_t* context);
 double pt_context_last_reduce_ms(const pt_context_t* context);
+/* Which of sample_count frames from first_frame_index on GPU gpu of
+ * gpu_count renders in pt_context_render_samples(): *out_sample_count frames
+ * (possibly none), the first at *out_first_frame_index, the others gpu_count
+ * apart. Host arithmetic only; needs no GPU. */
+int pt_context_frame_slice(uint32_t gpu, uint32_t gpu_count, uint32_t first_frame_index, uint32_t sample_count, uint32_t* out_first_frame_index, uint32_t* out_sample_count);
 
 /* Counters and timings since the last reset. Ray counts are the numbers of
  * extension and shadow rays actually traced (queue sizes). Node and triangle
@@ -208,6 +226,17 @@ typedef struct {
 	/* index: 0 raygen, 1 extension trace, 2 shadow trace, 3 shade, 4 resolve */
 	double kernel_ms[5];
 	uint64_t kernel_launches[5];
+	/* Whether shadow rays skip what cannot change their answer: 0 not decided
+	 * yet (they do, and the next batch decides), 1 yes, 2 no;
+	 * shadow_skipping_fixed is 1 when the environment variable
+	 * PT_SHADOW_SKIPPING fixed it. The decision was taken from
+	 * shadow_rays_decided_on rays of which shadow_rays_blocked ended at
+	 * something that is not emissive. It changes speed only, never the image;
+	 * reported so that timings of two runs can be compared. */
+	uint32_t shadow_skipping;
+	uint32_t shadow_skipping_fixed;
+	uint64_t shadow_rays_decided_on;
+	uint64_t shadow_rays_blocked;
 } pt_statistics_t;
 int pt_set_instrumentation(pt_scene_t* scene, int enable_kernel_timing, int enable_visit_counters);
 int pt_get_statistics(pt_scene_t* scene, pt_statistics_t* out_statistics);

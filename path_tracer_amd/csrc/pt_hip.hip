@@ -32,6 +32,7 @@
 #include <time.h>
 #include <exception>
 #include <new>
+#include <thread>
 #include <vector>
 
 static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device constants must agree");
@@ -762,6 +763,11 @@ struct pt_scene {
 	bool emissive_skipping_fixed;
 	bool emissive_skipping_last_vertex; // the rays to the last vertex of a path skip likewise (off with PT_SHADOW_SKIPPING=0)
 	uint32_t emissive_marks_index;
+	// What the decision was taken from (pt_statistics_t reports it), and the
+	// camera of the last pt_render_samples() call: another view has another
+	// share of blocked shadow rays, so the decision is taken anew for it
+	unsigned long long skipping_decided_on_rays, skipping_decided_on_blocked;
+	float skipping_camera[20];
 	// render targets and wavefront buffers
 	uint32_t width, height;
 	PtBatch frame_layout; // tiles and paths per frame
@@ -916,6 +922,8 @@ static void pt_collect(pt_scene* s) {
 		memcpy(&blocked, &c[PT_EMISSIVE_COUNTS_OFFSET + 2], sizeof(blocked));
 		if (s->emissive_skipping == 0 && s->pending_counter_reads[i].emissive_marks_serial == s->emissive_marks_serial && traced >= 4096) {
 			s->emissive_skipping = (4 * blocked >= traced) ? 1 : 2;
+			s->skipping_decided_on_rays = traced;
+			s->skipping_decided_on_blocked = blocked;
 			if (getenv("PT_TRACE_DIAGNOSTICS"))
 				printf("trace diagnostics (shadow): %.1f%% of %llu rays ended at a hit that is not emissive; skipping %s\n",
 					100.0 * (double) blocked / (double) traced, traced, (s->emissive_skipping == 1) ? "stays on" : "is turned off");
@@ -1225,6 +1233,8 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 	s->emissive_marks_valid = false;
 	s->emissive_marks_index = 0;
 	s->emissive_marks_serial = 0;
+	s->skipping_decided_on_rays = s->skipping_decided_on_blocked = 0;
+	memset(s->skipping_camera, 0, sizeof(s->skipping_camera));
 	// PT_SHADOW_SKIPPING=0 or 1 fixes what is otherwise decided by the rays
 	// traced so far (a knob for measurements; the images do not depend on it)
 	const char* skipping = getenv("PT_SHADOW_SKIPPING");
@@ -1684,6 +1694,23 @@ static int pt_render_samples_impl(pt_scene_t* s, const pt_constants_t* constants
 	if (pt_reserve_wavefront(s, s->frame_layout.paths_per_frame * frames_per_batch))
 		return 1;
 	PT_CHECK(hipMemcpyAsync(s->constants, constants, sizeof(PtConstants), hipMemcpyHostToDevice, s->stream));
+	// A target that holds no frame has nothing to add to: its first frame takes
+	// the discard pipeline whatever the caller says, as the reference does
+	// whenever accum_frame_count is zero (src/main.c:1884-1887), so alpha is 1
+	if (s->sample_count == 0)
+		accumulate = 0;
+	// Whether shadow rays skip was decided for the view it was measured on
+	float camera[20];
+	memcpy(camera, constants->world_to_projection_space, sizeof(float) * 16);
+	memcpy(camera + 16, constants->camera_pos, sizeof(float) * 3);
+	camera[19] = (float) constants->camera_type;
+	if (memcmp(camera, s->skipping_camera, sizeof(camera)) != 0) {
+		memcpy(s->skipping_camera, camera, sizeof(camera));
+		if (!s->emissive_skipping_fixed && s->emissive_skipping != 0) {
+			s->emissive_skipping = 0;
+			++s->emissive_marks_serial; // batches queued for the old view decide nothing
+		}
+	}
 	if (!accumulate)
 		s->sample_count = 0;
 	uint32_t done = 0;
@@ -1786,6 +1813,10 @@ static int pt_get_statistics_impl(pt_scene_t* s, pt_statistics_t* out) {
 				k ? "shadow" : "extension", visits[6 + 2 * k], 100.0 * (double) visits[7 + 2 * k] / (64.0 * (double) visits[6 + 2 * k]), visits[10 + 2 * k],
 				visits[16 + 2 * k], 100.0 * (double) visits[2 * k] / (64.0 * (double) visits[16 + 2 * k]), visits[17 + 2 * k], 100.0 * (double) visits[1 + 2 * k] / (64.0 * (double) visits[17 + 2 * k]));
 		}
+	s->stats.shadow_skipping = (uint32_t) s->emissive_skipping;
+	s->stats.shadow_skipping_fixed = s->emissive_skipping_fixed ? 1u : 0u;
+	s->stats.shadow_rays_decided_on = s->skipping_decided_on_rays;
+	s->stats.shadow_rays_blocked = s->skipping_decided_on_blocked;
 	*out = s->stats;
 	return 0;
 }
@@ -1798,6 +1829,17 @@ static int pt_reset_statistics_impl(pt_scene_t* s) {
 	memset(&s->stats, 0, sizeof(s->stats));
 	PT_CHECK(hipMemset(s->visit_counters, 0, PT_VISIT_COUNTERS * sizeof(unsigned long long)));
 	return 0;
+}
+
+extern "C" uint32_t pt_abi_version(void) { return PT_HIP_ABI_VERSION; }
+
+extern "C" uint32_t pt_get_device_count(void) {
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count < 0) {
+		(void) hipGetLastError();
+		return 0;
+	}
+	return (uint32_t) count;
 }
 
 extern "C" int pt_get_bvh_info(pt_scene_t* s, pt_bvh_info_t* out) {
@@ -2097,7 +2139,7 @@ static void pt_destroy_context_impl(pt_context* c) {
 		}
 	}
 	for (size_t i = 0; i != c->scenes.size(); ++i)
-		pt_destroy_scene(c->scenes[i]);
+		pt_destroy_scene(c->scenes[i]); // NULL where a replica was not created
 	delete c;
 }
 
@@ -2116,22 +2158,43 @@ static int pt_create_context_impl(pt_context** out_context, const int* device_id
 			}
 		}
 	}
-	if (pt_load_rccl())
+	// One GPU has nothing to sum: RCCL is loaded and communicators are made
+	// for two or more (PT_CONTEXT_FORCE_RCCL=1 takes the reduction through RCCL
+	// with one GPU as well, for tests on a one-GPU machine)
+	const char* force_rccl = getenv("PT_CONTEXT_FORCE_RCCL");
+	const bool use_rccl = device_count > 1 || (force_rccl && force_rccl[0] == '1');
+	if (use_rccl && pt_load_rccl())
 		return 1;
 	pt_context* c = new pt_context();
 	*out_context = c;
 	c->reduce_ms = 0.0;
 	c->devices.assign(device_ids, device_ids + device_count);
-	c->comms.assign(device_count, (ncclComm_t) NULL);
+	c->scenes.assign(device_count, (pt_scene*) NULL);
+	// The replicas are independent (upload, texture decode and BVH build on
+	// each GPU's own stream): one host thread per GPU creates them side by side
+	std::vector<int> results(device_count, 1);
+	auto create_replica = [&](uint32_t i) {
+		results[i] = pt_create_scene(&c->scenes[i], device_ids[i], header, positions, normals_and_tex_coords, material_indices, textures, texture_count);
+	};
+	if (device_count == 1)
+		create_replica(0);
+	else {
+		std::vector<std::thread> workers;
+		for (uint32_t i = 0; i != device_count; ++i)
+			workers.emplace_back(create_replica, i);
+		for (size_t i = 0; i != workers.size(); ++i)
+			workers[i].join();
+	}
 	for (uint32_t i = 0; i != device_count; ++i) {
-		pt_scene* scene = NULL;
-		if (pt_create_scene(&scene, device_ids[i], header, positions, normals_and_tex_coords, material_indices, textures, texture_count)) {
+		if (results[i]) {
 			printf("Failed to replicate the scene on GPU %d.\n", device_ids[i]);
 			return 1;
 		}
-		c->scenes.push_back(scene);
 	}
-	PT_RCCL_CHECK(pt_rccl.CommInitAll(c->comms.data(), (int) device_count, c->devices.data()));
+	if (use_rccl) {
+		c->comms.assign(device_count, (ncclComm_t) NULL);
+		PT_RCCL_CHECK(pt_rccl.CommInitAll(c->comms.data(), (int) device_count, c->devices.data()));
+	}
 	return 0;
 }
 
@@ -2203,21 +2266,26 @@ static int pt_context_reduce_impl(pt_context* c) {
 		if (pt_synchronize(c->scenes[g]))
 			return 1;
 	clock_gettime(CLOCK_MONOTONIC, &begin);
-	// One sum over xGMI: every GPU contributes its target, the first receives the total
-	PT_RCCL_CHECK(pt_rccl.GroupStart());
-	for (uint32_t g = 0; g != n; ++g) {
-		pt_scene* s = c->scenes[g];
-		PT_CHECK(pt_select_device(s->device));
-		PT_RCCL_CHECK(pt_rccl.Reduce(s->accum, s->accum, 4 * pixel_count, ncclFloat, ncclSum, 0, c->comms[g], s->stream));
+	// One sum over xGMI: every GPU contributes its target, the first receives
+	// the total. A context of one GPU has no communicators and nothing to sum
+	if (!c->comms.empty()) {
+		PT_RCCL_CHECK(pt_rccl.GroupStart());
+		for (uint32_t g = 0; g != n; ++g) {
+			pt_scene* s = c->scenes[g];
+			PT_CHECK(pt_select_device(s->device));
+			PT_RCCL_CHECK(pt_rccl.Reduce(s->accum, s->accum, 4 * pixel_count, ncclFloat, ncclSum, 0, c->comms[g], s->stream));
+		}
+		PT_RCCL_CHECK(pt_rccl.GroupEnd());
 	}
-	PT_RCCL_CHECK(pt_rccl.GroupEnd());
 	uint32_t total_samples = 0;
 	for (uint32_t g = 0; g != n; ++g) {
 		pt_scene* s = c->scenes[g];
 		total_samples += s->sample_count;
 		PT_CHECK(pt_select_device(s->device));
-		if (g == 0)
-			hipLaunchKernelGGL(k_reset_alpha, dim3(pt_grid(pixel_count)), dim3(PT_BLOCK), 0, s->stream, s->accum, (uint32_t) pixel_count);
+		if (g == 0) {
+			if (!c->comms.empty())
+				hipLaunchKernelGGL(k_reset_alpha, dim3(pt_grid(pixel_count)), dim3(PT_BLOCK), 0, s->stream, s->accum, (uint32_t) pixel_count);
+		}
 		else {
 			// What this GPU rendered is part of the total now; it starts over,
 			// so that another reduction after more frames counts nothing twice
@@ -2293,6 +2361,13 @@ extern "C" int pt_context_reduce(pt_context_t* context) {
 	return pt_guarded("pt_context_reduce", [&]() { return pt_context_reduce_impl(context); });
 }
 extern "C" double pt_context_last_reduce_ms(const pt_context_t* context) { return context ? context->reduce_ms : 0.0; }
+
+extern "C" int pt_context_frame_slice(uint32_t gpu, uint32_t gpu_count, uint32_t first_frame_index, uint32_t sample_count, uint32_t* out_first_frame_index, uint32_t* out_sample_count) {
+	if (gpu_count == 0 || gpu >= gpu_count || !out_first_frame_index || !out_sample_count)
+		return 1;
+	pt_context_slice(gpu, gpu_count, first_frame_index, sample_count, out_first_frame_index, out_sample_count);
+	return 0;
+}
 
 
 // ---------------------------------------------------------------- C ABI

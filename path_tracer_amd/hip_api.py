@@ -22,7 +22,9 @@ EXPORTED_SYMBOLS = [
     "pt_context_set_light_sampling", "pt_context_set_render_settings", "pt_context_create_render_targets",
     "pt_context_render_samples", "pt_context_synchronize", "pt_context_reduce", "pt_context_last_reduce_ms",
     "pt_trace_primary_rays", "pt_trace_rays", "pt_trace_rays_no_alloc", "pt_evaluate_shading_data", "pt_random_numbers",
+    "pt_abi_version", "pt_get_device_count", "pt_context_frame_slice",
 ]
+ABI_VERSION = 3  # PT_HIP_ABI_VERSION of the include/pt_hip.h that the structures below mirror
 
 
 class Constants(C.Structure):
@@ -59,7 +61,9 @@ class TextureDesc(C.Structure):
 class Statistics(C.Structure):
     _fields_ = [("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("paths", C.c_uint64),
                 ("nodes_visited", C.c_uint64 * 2), ("triangles_tested", C.c_uint64 * 2), ("shaded_hits", C.c_uint64),
-                ("kernel_ms", C.c_double * 5), ("kernel_launches", C.c_uint64 * 5)]
+                ("kernel_ms", C.c_double * 5), ("kernel_launches", C.c_uint64 * 5),
+                ("shadow_skipping", C.c_uint32), ("shadow_skipping_fixed", C.c_uint32),
+                ("shadow_rays_decided_on", C.c_uint64), ("shadow_rays_blocked", C.c_uint64)]
 
 
 class BvhInfo(C.Structure):
@@ -78,7 +82,11 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("%s is missing; build it with `make -C path_tracer_amd/csrc` (or __graft_entry__.build())" % LIB_PATH)
-        _lib = C.CDLL(LIB_PATH)
+        loaded = C.CDLL(LIB_PATH)
+        loaded.pt_abi_version.restype = C.c_uint32
+        if loaded.pt_abi_version() != ABI_VERSION:
+            raise RuntimeError("%s has ABI version %d, this binding was written for %d; rebuild it with `make -C path_tracer_amd/csrc`" % (LIB_PATH, loaded.pt_abi_version(), ABI_VERSION))
+        _lib = loaded
         vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int
         _lib.pt_create_scene.argtypes = [C.POINTER(vp), i32, C.POINTER(SceneHeader), vp, vp, vp, C.POINTER(TextureDesc), u32]
         _lib.pt_destroy_scene.argtypes = [vp]
@@ -118,6 +126,9 @@ def lib():
         _lib.pt_context_reduce.argtypes = [vp]
         _lib.pt_context_last_reduce_ms.argtypes = [vp]
         _lib.pt_context_last_reduce_ms.restype = C.c_double
+        _lib.pt_context_frame_slice.argtypes = [u32, u32, u32, u32, C.POINTER(u32), C.POINTER(u32)]
+        _lib.pt_get_device_count.argtypes = []
+        _lib.pt_get_device_count.restype = u32
     return _lib
 
 

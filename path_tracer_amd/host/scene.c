@@ -39,6 +39,10 @@ static int load_scene_on(scene_t* scene, const int* device_indices, uint32_t dev
 		printf("Loading the scene file at %s needs at least one GPU.\n", file_path);
 		return 1;
 	}
+	if (pt_abi_version() != PT_HIP_ABI_VERSION) {
+		printf("libpt_hip.so has ABI version %u but this host was built against version %u of pt_hip.h. Please rebuild both.\n", pt_abi_version(), PT_HIP_ABI_VERSION);
+		return 1;
+	}
 	FILE* file = fopen(file_path, "rb");
 	if (!file) {
 		printf("Failed to open the scene file at %s. Please check path and permissions.\n", file_path);

@@ -273,3 +273,18 @@ class Renderer:
 
     def __del__(self):
         self.close()
+
+
+class ReplicaView:
+    """Statistics and instrumentation of one replica of a multi-GPU renderer (pt_context_scene(context, i)); the
+    replica belongs to the renderer's context."""
+
+    def __init__(self, renderer, scene_handle):
+        self._renderer = renderer  # keeps the context alive
+        self._scene = C.c_void_p(scene_handle)
+
+    device_scene = property(lambda self: self._scene)
+    statistics = Renderer.statistics
+    reset_statistics = Renderer.reset_statistics
+    set_instrumentation = Renderer.set_instrumentation
+    bvh_info = Renderer.bvh_info

@@ -1,0 +1,82 @@
+"""bench.py on the one GPU of a test box: its one-process-many-GPUs code path (pt_create_context,
+pt_context_render_samples, pt_context_reduce) driven with a device list of one, checked against plain
+pt_render_samples() calls, and its refusal to measure fewer GPUs than it was asked for."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import bench
+from path_tracer_amd import hip_api, host_api
+from tests.paths import DATA, DATA_ROOT, ROOT
+from tests.test_gpu_parity import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def test_context_code_path_of_the_benchmark(monkeypatch):
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(name, raising=False)
+    width, height, spp, steps, warmup = 192, 108, 4, 3, 1
+    args = bench.parse_args(["--gpus", "1", "--force-context", "--workload", "cornell", "--width", str(width), "--height", str(height), "--spp-per-step", str(spp),
+                             "--steps", str(steps), "--warmup", str(warmup), "--strong-frames", "8", "--strong-steps", "2", "--no-cpu-baseline"])
+    image = []
+    result = bench.run(args, image_out=image)
+    assert result["n_gpus"] == 1 and result["scaling"] == "weak" and "pt_create_context" in result["config"]["parallelism"]
+    assert result["steps"] == steps and result["config"]["spp_total"] == steps * spp
+    # Ray conservation: what the GPUs report adds up to what the line's rates were computed from
+    per_gpu = result["per_gpu"]
+    assert len(per_gpu) == 1 and per_gpu[0]["device"] == 0 and per_gpu[0]["paths"] == width * height * spp * steps
+    rays = per_gpu[0]["extension_rays"] + per_gpu[0]["shadow_rays"]
+    assert abs(rays / per_gpu[0]["paths"] - result["rays_per_path"]) < 1e-12
+    seconds = result["ms_per_step"] * 1e-3 * steps
+    assert abs(rays / seconds * 1e-6 - result["value"]) < 1e-6 * result["value"]
+    for leg, frames in (("weak", spp), ("strong", 8)):
+        assert result[leg]["frames_per_step"] == frames and result[leg]["value"] > 0 and result[leg]["all_reduce_ms"] >= 0
+    assert result["shadow_skipping"]["state"] in ("on", "off") and result["shadow_skipping"]["decided_on_rays"] >= 4096
+    # The image of the timed leg equals plain pt_render_samples() calls for the same frames
+    got, count = image
+    first = result["weak"]["first_frame_index"]
+    spec = host_api.quickload(os.path.join(DATA, "saves", "cornell_box", "default.rt_save"))
+    assert first == spec.frame_index + 1 + (1 + warmup) * spp
+    single = host_api.Renderer(spec, DATA_ROOT, device=0, width=width, height=height)
+    constants = single.constants()
+    assert hip_api.lib().pt_render_samples(single.device_scene, C.byref(constants), first, steps * spp, 1, 0) == 0
+    expected, expected_count = single.read_accumulation()
+    single.close()
+    assert count == expected_count == steps * spp
+    assert (bits(got) == bits(expected)).all() and (got[..., 3] == 1.0).all()
+
+
+def test_benchmark_refuses_more_gpus_than_there_are():
+    visible = hip_api.lib().pt_get_device_count()
+    assert visible >= 1
+    environment = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(visible + 1), "--no-cpu-baseline", "--workload", "cornell"],
+                            capture_output=True, text=True, timeout=300, env=environment)
+    assert result.returncode != 0 and result.stdout.strip() == ""
+    assert "only %d GPU" % visible in result.stderr and "refusing" in result.stderr
+
+
+def test_accumulating_into_an_empty_target_takes_the_discard_pipeline():
+    """pt_render_samples(accumulate = 1) on a target that holds no frame behaves like accumulate = 0: the reference
+    binds the discard pipeline whenever accum_frame_count is zero (src/main.c:1884-1887), so alpha is 1."""
+    spec = host_api.quickload(os.path.join(DATA, "saves", "cornell_box", "default.rt_save"))
+    renderer = host_api.Renderer(spec, DATA_ROOT, device=0, width=64, height=48)
+    constants = renderer.constants()
+    lib = hip_api.lib()
+    assert lib.pt_render_samples(renderer.device_scene, C.byref(constants), 100, 3, 1, 1) == 0
+    fresh, count = renderer.read_accumulation()
+    assert count == 3 and (fresh[..., 3] == 1.0).all()
+    assert lib.pt_render_samples(renderer.device_scene, C.byref(constants), 100, 3, 1, 0) == 0
+    restarted, _ = renderer.read_accumulation()
+    assert (bits(fresh) == bits(restarted)).all()
+    # and a target emptied by pt_create_render_targets() or pt_set_sample_count(0) likewise
+    assert lib.pt_set_sample_count(renderer.device_scene, 0) == 0
+    assert lib.pt_render_samples(renderer.device_scene, C.byref(constants), 100, 3, 1, 1) == 0
+    again, count = renderer.read_accumulation()
+    assert count == 3 and (bits(again) == bits(fresh)).all()
+    renderer.close()

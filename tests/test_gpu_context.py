@@ -1,6 +1,7 @@
 """Several GPUs through the C ABI (pt_create_context, pt_context_render_samples, pt_context_reduce) and through
-the C host, on the one GPU a test box has: a context of one GPU takes the whole multi-GPU code path, RCCL
-reduction included, and must produce the bits of the single-scene path. The sharing of frames among GPUs itself
+the C host, on the one GPU a test box has: a context of one GPU takes the multi-GPU code path and must produce the
+bits of the single-scene path, both as it is (nothing to sum, RCCL not loaded) and with PT_CONTEXT_FORCE_RCCL=1,
+which sends the reduction through RCCL (communicator, grouped ncclReduce, alpha reset) as for several GPUs. The sharing of frames among GPUs itself
 (frame_stride) is covered by test_gpu_parity.py::test_sample_slices_1080p and tests/test_multi_gpu_cpu.py."""
 import ctypes as C
 import os
@@ -45,7 +46,9 @@ def create_context(scene, devices):
     return code, context
 
 
-def test_context_of_one_gpu_renders_the_bits_of_a_scene():
+@pytest.mark.parametrize("force_rccl", ["0", "1"])
+def test_context_of_one_gpu_renders_the_bits_of_a_scene(force_rccl, monkeypatch):
+    monkeypatch.setenv("PT_CONTEXT_FORCE_RCCL", force_rccl)
     lib = hip_api.lib()
     scene = synthetic.triangle_soup(seed=31, triangle_count=6000, material_count=3, texture_size=32)
     lights = synthetic.random_lights(5, 7)

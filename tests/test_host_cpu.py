@@ -38,7 +38,10 @@ def test_host_library_exports():
 def test_abi_struct_sizes():
     assert C.sizeof(hip_api.Constants) == 784
     assert C.sizeof(host_api.SceneSpec) == 128
-    assert C.sizeof(hip_api.Statistics) == 8 * 8 + 5 * 8 + 5 * 8
+    assert C.sizeof(hip_api.Statistics) == 8 * 8 + 5 * 8 + 5 * 8 + 2 * 4 + 2 * 8
+    assert hip_api.lib().pt_abi_version() == hip_api.ABI_VERSION
+    header = open(os.path.join(ROOT, "include", "pt_hip.h")).read()
+    assert int(re.search(r"#define PT_HIP_ABI_VERSION (\d+)u", header).group(1)) == hip_api.ABI_VERSION
 
 
 def test_invert_mat4_bitwise_against_oracle():
@@ -193,6 +196,39 @@ def test_frame_slices_partition_the_sample_set():
             assert sorted(covered) == list(range(2696, 2696 + total))
     with pytest.raises(ValueError):
         multi_gpu.frame_slice(4, 4, 0, 10)
+
+
+def test_library_frame_slices_partition_the_sample_set():
+    """What pt_context_render_samples() hands each GPU (pt_context_frame_slice): the union of the slices is the
+    sample set, each frame once, also when there are fewer frames than GPUs, and it equals the Python slices that the
+    one-process-per-GPU path uses."""
+    lib = hip_api.lib()
+    for gpus in (1, 2, 3, 4, 7, 8):
+        for total in (0, 1, 2, 5, 7, 8, 9, 64, 1023):
+            covered = []
+            for gpu in range(gpus):
+                first, count = C.c_uint32(), C.c_uint32()
+                assert lib.pt_context_frame_slice(gpu, gpus, 816, total, C.byref(first), C.byref(count)) == 0
+                assert (first.value, count.value, gpus) == multi_gpu.frame_slice(gpu, gpus, 816, total)
+                if total <= gpu:
+                    assert count.value == 0
+                covered += [first.value + i * gpus for i in range(count.value)]
+            assert sorted(covered) == list(range(816, 816 + total))
+    out = C.c_uint32()
+    assert lib.pt_context_frame_slice(2, 2, 0, 4, C.byref(out), C.byref(out)) != 0
+    assert lib.pt_context_frame_slice(0, 0, 0, 4, C.byref(out), C.byref(out)) != 0
+    assert lib.pt_context_frame_slice(0, 1, 0, 4, None, C.byref(out)) != 0
+
+
+def test_bench_refuses_to_run_without_the_gpus_it_was_asked_for():
+    """No GPU here: the benchmark must say so and fail, whatever --gpus asks for (on a box with one GPU the GPU
+    suite checks that --gpus 2 is refused likewise)."""
+    import subprocess
+    import sys
+    for gpus in ("1", "2"):
+        result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", gpus, "--no-cpu-baseline", "--workload", "cornell"], capture_output=True, text=True, timeout=300)
+        if hip_api.lib().pt_get_device_count() == 0:
+            assert result.returncode != 0 and "needs a GPU" in result.stderr and result.stdout.strip() == ""
 
 
 def test_write_jpg_decodes_close_to_input(tmp_path):

@@ -290,6 +290,30 @@ int pt_evaluate_shading_data(pt_scene_t* scene, const pt_constants_t* constants,
 	const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, const float* footprints,
 	uint32_t count, float* out_shading_data);
 
+/* Test hook: one sampler, density or BRDF of the shaders for explicit
+ * arguments, so that normalisation and the agreement of every sampler with
+ * its density can be tested without rendering. shading_data holds the 20
+ * floats of one shading_data_t (src/shaders/shading_data.glsl:19-39) shared by
+ * all evaluations; inputs and outputs hold four floats per evaluation. A
+ * sampler takes two random numbers (x, y) and returns a world-space direction
+ * (x, y, z); a density or the BRDF takes a world-space direction (x, y, z).
+ * The lights are those of pt_set_lights(). */
+enum {
+	PT_FUNCTION_SAMPLE_GGX_IN_DIR = 0,          /* src/shaders/brdfs.glsl:104-107 in the frame of :126-134 */
+	PT_FUNCTION_GGX_IN_DIR_DENSITY = 1,         /* brdfs.glsl:112-121 -> x */
+	PT_FUNCTION_SAMPLE_HEMISPHERE_PSA = 2,      /* brdfs.glsl:139-146 */
+	PT_FUNCTION_HEMISPHERE_PSA_DENSITY = 3,     /* brdfs.glsl:151-153 -> x */
+	PT_FUNCTION_SAMPLE_HEMISPHERE_SPHERICAL = 4, /* src/shaders/pathtrace.frag.glsl:50-55 */
+	PT_FUNCTION_HEMISPHERE_SPHERICAL_DENSITY = 5, /* pathtrace.frag.glsl:60-64 -> x */
+	PT_FUNCTION_SAMPLE_FROSTBITE_BRDF = 6,      /* brdfs.glsl:174-199 */
+	PT_FUNCTION_FROSTBITE_BRDF_DENSITY = 7,     /* brdfs.glsl:203-208 -> x */
+	PT_FUNCTION_FROSTBITE_BRDF = 8,             /* brdfs.glsl:19-46 -> x, y, z */
+	PT_FUNCTION_SAMPLE_LIGHTS = 9,              /* pathtrace.frag.glsl:120-143; w receives the total importance */
+	PT_FUNCTION_LIGHTS_DENSITY = 10,            /* pathtrace.frag.glsl:150-175: x for a direction towards a light, y for any other, z the total importance */
+	PT_FUNCTION_COUNT = 11
+};
+int pt_evaluate_function(pt_scene_t* scene, int function, const float* shading_data, const float* inputs, uint32_t count, float* outputs);
+
 /* Test hook: the first draw_count pairs of get_random_numbers()
  * (src/shaders/pathtrace.frag.glsl:23-34) for the seed of pixel (x, y) in
  * frame frame_index (:368), computed on the GPU. */

@@ -70,6 +70,7 @@ def lib():
         _lib.oracle_shading_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.oracle_primary_cones.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.oracle_sample_texture.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.oracle_evaluate_function.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.oracle_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
         _lib.oracle_log.restype = C.c_float
         _lib.oracle_log.argtypes = [C.c_float]
@@ -168,6 +169,18 @@ class OracleScene:
         lods = None if lods is None else np.ascontiguousarray(lods, np.float32).reshape(-1)
         lib().oracle_sample_texture(self.handle, texture_index, _ptr(uvs), None if lods is None else _ptr(lods), len(uvs), _ptr(out))
         return out
+
+
+def evaluate_function(function, shading_data, inputs, lights=None):
+    """oracle_evaluate_function(): inputs (n, <= 4) floats -> (n, 4) floats."""
+    shading_data = np.ascontiguousarray(shading_data, np.float32).reshape(20)
+    inputs = np.atleast_2d(np.asarray(inputs, np.float32))
+    padded = np.zeros((len(inputs), 4), np.float32)
+    padded[:, :inputs.shape[1]] = inputs
+    lights = np.zeros((0, 4), np.float32) if lights is None else np.ascontiguousarray(lights, np.float32).reshape(-1, 4)
+    out = np.zeros((len(padded), 4), np.float32)
+    lib().oracle_evaluate_function(function, _ptr(shading_data), _ptr(lights), len(lights), _ptr(padded), len(padded), _ptr(out))
+    return out
 
 
 def rng_stream(x, y, frame_index, draw_count):

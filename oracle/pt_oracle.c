@@ -1554,6 +1554,58 @@ void oracle_shading_data(const oracle_scene_t* scene, const oracle_constants_t* 
 	}
 }
 
+/* One sampler, density or BRDF for explicit arguments (see pt_oracle.h) */
+void oracle_evaluate_function(int function, const float* shading_data, const float* lights, uint32_t light_count, const float* inputs, uint32_t count, float* outputs) {
+	shading_data_t s;
+	s.pos = v3(shading_data[0], shading_data[1], shading_data[2]);
+	s.normal = v3(shading_data[3], shading_data[4], shading_data[5]);
+	s.out_dir = v3(shading_data[6], shading_data[7], shading_data[8]);
+	s.lambert_out = shading_data[9];
+	s.emission = v3(shading_data[10], shading_data[11], shading_data[12]);
+	s.diffuse_albedo = v3(shading_data[13], shading_data[14], shading_data[15]);
+	s.fresnel_0 = v3(shading_data[16], shading_data[17], shading_data[18]);
+	s.roughness = shading_data[19];
+	context_t ctx;
+	memset(&ctx, 0, sizeof(ctx));
+	ctx.lights = lights;
+	ctx.light_count = light_count;
+	mat3_t shading_to_world_space = get_shading_space(s.normal);
+	for (uint32_t i = 0; i != count; ++i) {
+		const float* in = &inputs[4 * (size_t) i];
+		float* out = &outputs[4 * (size_t) i];
+		vec2 randoms = { in[0], in[1] };
+		vec3 dir = v3(in[0], in[1], in[2]);
+		vec3 result = v3(0.0f, 0.0f, 0.0f);
+		float last = 0.0f;
+		switch (function) {
+		case 0: result = mat3_mul(&shading_to_world_space, sample_ggx_in_dir(mat3_transpose_mul(&shading_to_world_space, s.out_dir), s.roughness, randoms)); break;
+		case 1: result.x = get_ggx_in_dir_density(s.lambert_out, s.out_dir, dir, s.normal, s.roughness); break;
+		case 2: result = mat3_mul(&shading_to_world_space, sample_hemisphere_psa(randoms)); break;
+		case 3: result.x = get_hemisphere_psa_density(dot3(s.normal, dir)); break;
+		case 4: result = mat3_mul(&shading_to_world_space, sample_hemisphere_spherical(randoms)); break;
+		case 5: result.x = get_hemisphere_spherical_density(dot3(s.normal, dir)); break;
+		case 6: result = sample_frostbite_brdf(&s, randoms); break;
+		case 7: result.x = get_frostbite_brdf_density(&s, dir); break;
+		case 8: result = frostbite_brdf(&s, dir); break;
+		case 9: result = sample_lights(&ctx, &last, s.pos, s.normal, randoms); break;
+		case 10: {
+			float total = 0.0f;
+			for (uint32_t j = 0; j != light_count; ++j)
+				total += get_spherical_light_importance(v3(lights[4 * j], lights[4 * j + 1], lights[4 * j + 2]), lights[4 * j + 3], s.pos, s.normal);
+			result.x = get_lights_density(&ctx, total, s.pos, s.normal, dir, 1);
+			result.y = get_lights_density(&ctx, total, s.pos, s.normal, dir, 0);
+			result.z = total;
+			break;
+		}
+		default: break;
+		}
+		out[0] = result.x;
+		out[1] = result.y;
+		out[2] = result.z;
+		out[3] = last;
+	}
+}
+
 void oracle_sample_texture(const oracle_scene_t* scene, uint32_t texture_index, const float* uvs, const float* lods, uint32_t count, float* out) {
 	for (uint32_t i = 0; i != count; ++i) {
 		vec2 uv = { uvs[2 * i], uvs[2 * i + 1] };

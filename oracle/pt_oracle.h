@@ -7,15 +7,21 @@
  * the cpu_baseline leg of bench.py do.
  *
  * Parity status: the reference ships no tests, golden images or known-answer
- * vectors and cannot be built in this environment (it needs Vulkan with ray
- * queries, GLFW, a display and glslangValidator), so the oracle is pinned
- * only by (a) the published PCG2D algorithm and hand-derived known answers,
- * (b) facts parsed from the reference's own data files and (c) internal
- * consistency of its four unbiased estimators. Ray/triangle intersection and
- * texture filtering happen inside the Vulkan driver in the reference and are
- * "parity unpinned": the oracle defines them (watertight ray/triangle test,
- * float trilinear filtering of hand-decoded BC1/BC5 blocks at a level of
- * detail taken from the footprint of the path, a ray cone).
+ * vectors, and its renderer cannot be built in this environment (it needs
+ * Vulkan with ray queries, GLFW, a display and glslangValidator). What pins
+ * the oracle: (a) the published PCG2D algorithm and hand-derived known
+ * answers, (b) facts parsed from the reference's own data files, (c) outputs
+ * of the reference's own C where it compiles alone (math_utilities.c, the
+ * texture converter, stb_image_write; oracle/Makefile target "ref", fixtures
+ * under tests/golden/ref), (d) properties that hold for any correct
+ * restatement: every density integrates to one, every sampler follows its
+ * density, a surface under a uniform sky reflects the directional albedo that
+ * a double-precision numpy restatement of frostbite_brdf() gives, and the four
+ * estimators agree (tests/test_estimator_pins.py). Ray/triangle intersection
+ * and texture filtering happen inside the Vulkan driver in the reference and
+ * are "parity unpinned": the oracle defines them (watertight ray/triangle
+ * test, float trilinear filtering of hand-decoded BC1/BC5 blocks at a level
+ * of detail taken from the footprint of the path, a ray cone).
  */
 #ifndef PT_ORACLE_H
 #define PT_ORACLE_H
@@ -122,6 +128,22 @@ void oracle_shading_data(const oracle_scene_t* scene, const oracle_constants_t* 
  * each) and levels of detail (NULL = level 0), trilinearly; writes 3 floats
  * per sample (BC5: r, g, 0). */
 void oracle_sample_texture(const oracle_scene_t* scene, uint32_t texture_index, const float* uvs, const float* lods, uint32_t count, float* out);
+
+/* One sampler, density or BRDF of the shaders for explicit arguments, for
+ * tests of normalisation and of sampler against density. shading_data: the 20
+ * floats of one shading_data_t; inputs and outputs: four floats per
+ * evaluation (a sampler takes two random numbers and returns a world-space
+ * direction, a density or the BRDF takes a world-space direction). function:
+ * 0 sample_ggx_in_dir (brdfs.glsl:104-107, in the frame of :126-134),
+ * 1 get_ggx_in_dir_density (:112-121), 2 sample_hemisphere_psa (:139-146),
+ * 3 get_hemisphere_psa_density (:151-153), 4 sample_hemisphere_spherical
+ * (pathtrace.frag.glsl:50-55), 5 get_hemisphere_spherical_density (:60-64),
+ * 6 sample_frostbite_brdf (brdfs.glsl:174-199), 7 get_frostbite_brdf_density
+ * (:203-208), 8 frostbite_brdf (:19-46), 9 sample_lights
+ * (pathtrace.frag.glsl:120-143; fourth output: total importance),
+ * 10 get_lights_density (:150-175; outputs: for a direction towards a light,
+ * for any other direction, the total importance). */
+void oracle_evaluate_function(int function, const float* shading_data, const float* lights, uint32_t light_count, const float* inputs, uint32_t count, float* outputs);
 
 /* Elementary functions shared by definition with the HIP kernels. */
 void oracle_sincos(float x, float* out_sin, float* out_cos);

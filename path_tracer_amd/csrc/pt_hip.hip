@@ -2041,6 +2041,51 @@ static int pt_evaluate_shading_data_impl(pt_scene_t* s, const pt_constants_t* co
 	return result;
 }
 
+__global__ void __launch_bounds__(PT_BLOCK) k_evaluate_function(PtSceneView scene, int function, const float* shading_data, const float* inputs, uint32_t count, float* outputs) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i >= count)
+		return;
+	float s[20], in[4], out[4];
+	for (int j = 0; j != 20; ++j)
+		s[j] = shading_data[j];
+	for (int j = 0; j != 4; ++j)
+		in[j] = inputs[4 * (uint64_t) i + j];
+	pt_evaluate_function(scene, function, s, in, out);
+	for (int j = 0; j != 4; ++j)
+		outputs[4 * (uint64_t) i + j] = out[j];
+}
+
+static int pt_evaluate_function_impl(pt_scene_t* s, int function, const float* shading_data, const float* inputs, uint32_t count, float* outputs) {
+	if (!s || !shading_data || (count && (!inputs || !outputs)))
+		return 1;
+	if (function < 0 || function >= PT_FUNCTION_COUNT) {
+		printf("pt_evaluate_function() knows the functions 0 to %d, got %d.\n", PT_FUNCTION_COUNT - 1, function);
+		return 1;
+	}
+	if (count == 0)
+		return 0;
+	PT_CHECK(pt_select_device(s->device));
+	PT_CHECK(hipStreamSynchronize(s->stream));
+	float* d_shading_data = NULL; float* d_inputs = NULL; float* d_outputs = NULL;
+	int result = 1;
+	do {
+		if (pt_alloc(&d_shading_data, 20) || pt_alloc(&d_inputs, 4 * (uint64_t) count) || pt_alloc(&d_outputs, 4 * (uint64_t) count))
+			break;
+		if (hipMemcpyAsync(d_shading_data, shading_data, sizeof(float) * 20, hipMemcpyHostToDevice, s->stream) != hipSuccess
+			|| hipMemcpyAsync(d_inputs, inputs, sizeof(float) * 4 * count, hipMemcpyHostToDevice, s->stream) != hipSuccess)
+			break;
+		hipLaunchKernelGGL(k_evaluate_function, dim3(pt_grid(count)), dim3(PT_BLOCK), 0, s->stream, pt_scene_view(s), function, d_shading_data, d_inputs, count, d_outputs);
+		if (hipMemcpyAsync(outputs, d_outputs, sizeof(float) * 4 * count, hipMemcpyDeviceToHost, s->stream) != hipSuccess
+			|| hipStreamSynchronize(s->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+			break;
+		result = 0;
+	} while (0);
+	hipFree(d_shading_data); hipFree(d_inputs); hipFree(d_outputs);
+	if (result)
+		printf("Failed to evaluate function %d on the GPU.\n", function);
+	return result;
+}
+
 extern "C" int pt_random_numbers(int device_index, uint32_t x, uint32_t y, uint32_t frame_index, uint32_t draw_count, float* out_randoms) {
 	if (!out_randoms && draw_count)
 		return 1;
@@ -2429,6 +2474,10 @@ extern "C" int pt_trace_rays(pt_scene_t* scene, const float* origins, const floa
 
 extern "C" int pt_evaluate_shading_data(pt_scene_t* scene, const pt_constants_t* constants, const int32_t* triangle_indices, const float* barycentrics, const uint8_t* front, const float* out_dirs, const float* footprints, uint32_t count, float* out_shading_data) {
 	return pt_guarded("pt_evaluate_shading_data", [&]() { return pt_evaluate_shading_data_impl(scene, constants, triangle_indices, barycentrics, front, out_dirs, footprints, count, out_shading_data); });
+}
+
+extern "C" int pt_evaluate_function(pt_scene_t* scene, int function, const float* shading_data, const float* inputs, uint32_t count, float* outputs) {
+	return pt_guarded("pt_evaluate_function", [&]() { return pt_evaluate_function_impl(scene, function, shading_data, inputs, count, outputs); });
 }
 
 extern "C" int pt_trace_rays_no_alloc(pt_scene_t* scene, const float* device_origins, const float* device_directions, uint32_t ray_count, int32_t* device_triangle_indices, float* device_t_u_v, uint8_t* device_front) {

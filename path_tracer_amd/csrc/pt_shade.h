@@ -1213,3 +1213,58 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 	}
 	return r;
 }
+
+
+// ---- Test hook: one sampler, density or BRDF of brdfs.glsl /
+// pathtrace.frag.glsl for explicit arguments, so that tests can check
+// normalisation (the integral of a density is 1) and that every sampler
+// follows its density without rendering anything. shading_data holds the 20
+// floats of shading_data_t (shading_data.glsl:19-39), input and output four
+// floats each; the functions are numbered like PT_FUNCTION_* in pt_hip.h.
+PT_FN void pt_evaluate_function(const PtSceneView& scene, int function, const float* shading_data, const float* input, float* output) {
+	PtShadingData s;
+	s.pos = mk3(shading_data[0], shading_data[1], shading_data[2]);
+	s.normal = mk3(shading_data[3], shading_data[4], shading_data[5]);
+	s.out_dir = mk3(shading_data[6], shading_data[7], shading_data[8]);
+	s.lambert_out = shading_data[9];
+	s.emission = mk3(shading_data[10], shading_data[11], shading_data[12]);
+	s.diffuse_albedo = mk3(shading_data[13], shading_data[14], shading_data[15]);
+	s.fresnel_0 = mk3(shading_data[16], shading_data[17], shading_data[18]);
+	s.roughness = shading_data[19];
+	s.footprint = 0.0f;
+	v2 randoms = mk2(input[0], input[1]);
+	v3 dir = mk3(input[0], input[1], input[2]);
+	PtFrame frame = pt_shading_space(s.normal);
+	v3 result = mk3(0.0f, 0.0f, 0.0f);
+	float last = 0.0f;
+	PtLightCache no_cache;
+	no_cache.values = NULL;
+	no_cache.stride = no_cache.capacity = 0;
+	switch (function) {
+	case 0: result = pt_to_world(frame, pt_sample_ggx_in_dir(pt_to_local(frame, s.out_dir), s.roughness, randoms)); break;
+	case 1: result.x = pt_ggx_in_dir_density(s.lambert_out, s.out_dir, dir, s.normal, s.roughness); break;
+	case 2: result = pt_to_world(frame, pt_sample_hemisphere_psa(randoms)); break;
+	case 3: result.x = pt_hemisphere_psa_density(dot(s.normal, dir)); break;
+	case 4: result = pt_to_world(frame, pt_sample_hemisphere_spherical(randoms)); break;
+	case 5: result.x = pt_hemisphere_spherical_density(dot(s.normal, dir)); break;
+	case 6: result = pt_sample_frostbite_brdf(s, randoms); break;
+	case 7: result.x = pt_frostbite_brdf_density(s, dir); break;
+	case 8: result = pt_frostbite_brdf(s, dir); break;
+	case 9: result = pt_sample_lights(scene, no_cache, &last, s.pos, s.normal, randoms); break;
+	case 10: {
+		// get_lights_density() for a direction towards a light (x) and for any
+		// other direction (y); z is the total importance it was given
+		float total = 0.0f;
+		for (uint32_t i = 0; i != scene.light_count; ++i)
+			total += pt_spherical_light_importance(pt_light(scene, i), s.pos, s.normal);
+		pt_lights_density_2(scene, total, s.pos, dir, dir, &result.x, &result.y);
+		result.z = total;
+		break;
+	}
+	default: break;
+	}
+	output[0] = result.x;
+	output[1] = result.y;
+	output[2] = result.z;
+	output[3] = last;
+}

@@ -22,7 +22,7 @@ EXPORTED_SYMBOLS = [
     "pt_context_set_light_sampling", "pt_context_set_render_settings", "pt_context_create_render_targets",
     "pt_context_render_samples", "pt_context_synchronize", "pt_context_reduce", "pt_context_last_reduce_ms",
     "pt_trace_primary_rays", "pt_trace_rays", "pt_trace_rays_no_alloc", "pt_evaluate_shading_data", "pt_random_numbers",
-    "pt_abi_version", "pt_get_device_count", "pt_context_frame_slice",
+    "pt_abi_version", "pt_get_device_count", "pt_context_frame_slice", "pt_evaluate_function",
 ]
 ABI_VERSION = 3  # PT_HIP_ABI_VERSION of the include/pt_hip.h that the structures below mirror
 
@@ -110,6 +110,7 @@ def lib():
         _lib.pt_trace_rays_no_alloc.argtypes = [vp, vp, vp, u32, vp, vp, vp]
         _lib.pt_evaluate_shading_data.argtypes = [vp, C.POINTER(Constants), vp, vp, vp, vp, vp, u32, vp]
         _lib.pt_random_numbers.argtypes = [i32, u32, u32, u32, u32, vp]
+        _lib.pt_evaluate_function.argtypes = [vp, i32, vp, vp, u32, vp]
         _lib.pt_create_context.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), u32, C.POINTER(SceneHeader), vp, vp, vp, C.POINTER(TextureDesc), u32]
         _lib.pt_destroy_context.argtypes = [vp]
         _lib.pt_destroy_context.restype = None
@@ -255,6 +256,21 @@ class Scene:
         _check(lib().pt_evaluate_shading_data(self.handle, C.byref(constants), _ptr(triangles), _ptr(barys), _ptr(front), _ptr(out_dirs),
                                                   None if footprints is None else _ptr(np.ascontiguousarray(footprints, np.float32).reshape(-1)), len(triangles), _ptr(out)), "pt_evaluate_shading_data")
         return out
+
+    def evaluate_function(self, function, shading_data, inputs):
+        """pt_evaluate_function(): inputs (n, <= 4) floats -> (n, 4) floats."""
+        shading_data = np.ascontiguousarray(shading_data, np.float32).reshape(20)
+        inputs = np.atleast_2d(np.asarray(inputs, np.float32))
+        padded = np.zeros((len(inputs), 4), np.float32)
+        padded[:, :inputs.shape[1]] = inputs
+        out = np.zeros((len(padded), 4), np.float32)
+        _check(lib().pt_evaluate_function(self.handle, function, _ptr(shading_data), _ptr(padded), len(padded), _ptr(out)), "pt_evaluate_function")
+        return out
+
+
+(FUNCTION_SAMPLE_GGX_IN_DIR, FUNCTION_GGX_IN_DIR_DENSITY, FUNCTION_SAMPLE_HEMISPHERE_PSA, FUNCTION_HEMISPHERE_PSA_DENSITY,
+ FUNCTION_SAMPLE_HEMISPHERE_SPHERICAL, FUNCTION_HEMISPHERE_SPHERICAL_DENSITY, FUNCTION_SAMPLE_FROSTBITE_BRDF, FUNCTION_FROSTBITE_BRDF_DENSITY,
+ FUNCTION_FROSTBITE_BRDF, FUNCTION_SAMPLE_LIGHTS, FUNCTION_LIGHTS_DENSITY) = range(11)
 
 
 def random_numbers(x, y, frame_index, draw_count, device=0):

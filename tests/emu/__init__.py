@@ -56,6 +56,7 @@ def lib():
         _lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
         _lib.emu_primary_cones.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         _lib.emu_shading_data.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        _lib.emu_evaluate_function.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         _lib.emu_sincos.argtypes = [C.c_float, C.c_void_p, C.c_void_p]
         _lib.emu_log.restype = C.c_float
         _lib.emu_log.argtypes = [C.c_float]
@@ -106,6 +107,16 @@ class EmuScene:
     def set_lights(self, lights):
         lights = np.ascontiguousarray(lights, np.float32).reshape(-1, 4)
         lib().emu_set_lights(self.handle, _ptr(lights), len(lights))
+
+    def evaluate_function(self, function, shading_data, inputs):
+        """pt_evaluate_function() of the kernel bodies: inputs (n, <= 4) floats -> (n, 4) floats."""
+        shading_data = np.ascontiguousarray(shading_data, np.float32).reshape(20)
+        inputs = np.atleast_2d(np.asarray(inputs, np.float32))
+        padded = np.zeros((len(inputs), 4), np.float32)
+        padded[:, :inputs.shape[1]] = inputs
+        out = np.zeros((len(padded), 4), np.float32)
+        lib().emu_evaluate_function(self.handle, function, _ptr(shading_data), _ptr(padded), len(padded), _ptr(out))
+        return out
 
     def light_grid_mismatches(self, origins, directions):
         """(rays whose lights found through the grid differ from a loop over all lights, rays that met more than four

@@ -543,6 +543,13 @@ void emu_shading_data(EmuScene* s, const PtConstants* c, uint32_t emission_mater
 	}
 }
 
+// pt_evaluate_function() of the kernel bodies, evaluated serially (the numbering is PT_FUNCTION_* of include/pt_hip.h)
+void emu_evaluate_function(EmuScene* s, int function, const float* shading_data, const float* inputs, uint32_t count, float* outputs) {
+	PtSceneView view = s->view();
+	for (uint32_t i = 0; i != count; ++i)
+		pt_evaluate_function(view, function, shading_data, inputs + 4 * (size_t) i, outputs + 4 * (size_t) i);
+}
+
 void emu_sincos(float x, float* s, float* c) { pt_sincos(x, s, c); }
 float emu_log(float x) { return pt_log(x); }
 float emu_erfinv(float x) { return pt_erfinv(x); }

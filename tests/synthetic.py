@@ -161,3 +161,42 @@ def look_at_spec(position, angles, frame_index=100, sky=(0.2, 0.4, 1.0), sky_str
     spec["emission_material_strength"] = emission_strength
     spec["type"] = camera_type
     return spec
+
+
+def constant_texture(value, fmt, size=4):
+    """A texture of one colour (linear values in [0, 1]; two channels for format 141), written by the authoring tool
+    of this repository and read back by the numpy parser."""
+    import os
+    import tempfile
+    from path_tracer_amd.tools import vkt
+    image = np.broadcast_to(np.asarray(value, np.float64), (size, size, len(value))).copy()
+    with tempfile.TemporaryDirectory() as directory:
+        path = os.path.join(directory, "constant.vkt")
+        vkt.write_vkt(path, image, fmt)
+        return formats.load_vkt(path)
+
+
+def furnace_scene(base_color=(1.0, 1.0, 1.0), roughness=0.5, metalicity=0.0, walls=False, half_extent=100.0):
+    """A floor in the plane z = 0 (normals +z) of one material with constant textures and no emitter: under a sky of
+    unit radiance a convex surface reflects exactly its directional albedo. With walls: a box of the same material,
+    open at the top, inside which light bounces several times. The specular texture stores (unused, square root of
+    the roughness, metalicity) as shading_data.glsl:96-102 reads it, the normal texture the flat normal."""
+    h = half_extent
+    quads = [[(-h, -h, 0), (h, -h, 0), (h, h, 0), (-h, h, 0)]]
+    if walls:
+        w, t = 1.0, 1.5
+        quads = [[(-w, -w, 0), (w, -w, 0), (w, w, 0), (-w, w, 0)],
+                 [(-w, -w, 0), (-w, w, 0), (-w, w, t), (-w, -w, t)], [(w, w, 0), (w, -w, 0), (w, -w, t), (w, w, t)],
+                 [(w, -w, 0), (-w, -w, 0), (-w, -w, t), (w, -w, t)], [(-w, w, 0), (w, w, 0), (w, w, t), (-w, w, t)]]
+    tris = []
+    for q in quads:
+        tris += [[q[0], q[1], q[2]], [q[0], q[2], q[3]]]
+    verts = np.array(tris, np.float64)
+    positions, factor, summand = quantize_positions(verts.reshape(-1, 3))
+    geometric = np.cross(verts[:, 1] - verts[:, 0], verts[:, 2] - verts[:, 0])
+    geometric /= np.linalg.norm(geometric, axis=1, keepdims=True)
+    uv = np.tile(np.array([[0, 0], [4096, 0], [4096, 4096]], np.uint16), (len(tris), 1))
+    normals_uvs = np.concatenate([encode_octahedral(np.repeat(geometric, 3, axis=0)), uv], axis=1).astype(np.uint16)
+    surface = [constant_texture(base_color, 132), constant_texture((0.0, np.sqrt(roughness), metalicity), 131), constant_texture((0.5, 0.5), 141)]
+    unused = [constant_texture((0.0, 0.0, 0.0), 132), constant_texture((0.0, 1.0, 0.0), 131), constant_texture((0.5, 0.5), 141)]
+    return formats.Scene(["_emission", "surface"], len(tris), factor, summand, positions, normals_uvs, np.ones(len(tris), np.uint8), unused + surface)

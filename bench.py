@@ -90,6 +90,8 @@ def parse_args(argv=None):
                    help="replace the workload's lights by this many spheres placed uniformly in the scene's bounding box (seed 4, radius 0.1 to 0.5)")
     p.add_argument("--light-sampling", choices=("loop", "tree"), default="loop",
                    help="loop: the reference's loops over all lights per vertex; tree: one descent through the light tree")
+    p.add_argument("--shading-math", choices=("exact", "fast"), default="exact",
+                   help="exact: correctly rounded divisions and square roots in the loops over all lights (images equal the CPU oracle bit for bit); fast: the GPU's approximate reciprocal and square root there")
     p.add_argument("--scene-cache", default=os.path.join(os.environ.get("TMPDIR", "/tmp"), "pt_scenes"))
     return p.parse_args(argv)
 
@@ -367,6 +369,9 @@ def run(args, image_out=None):
             raise RuntimeError("pt_set_lights failed")
         light_count = len(lights)
     renderer.set_light_sampling(hip_api.LIGHT_SAMPLING_TREE if args.light_sampling == "tree" else hip_api.LIGHT_SAMPLING_EXACT)
+    shading_math = hip_api.SHADING_MATH_FAST if args.shading_math == "fast" else hip_api.SHADING_MATH_EXACT
+    if (lib.pt_context_set_shading_math(backend.context, shading_math) if use_context else lib.pt_set_shading_math(renderer.device_scene, shading_math)):
+        raise RuntimeError("pt_set_shading_math failed")
 
     spp = args.spp_per_step
     next_frame = [spec.frame_index + 1]
@@ -418,7 +423,7 @@ def run(args, image_out=None):
         d = kernels[dominant]
         # Counters exist for the configurations that were profiled: the default batch of the workloads as they are
         profiled = spp == 32 and not args.triangles and args.lights is None and not args.texture_size and args.light_sampling == "loop" \
-            and (args.width, args.height, args.path_length) == (1920, 1080, 4) and args.scaling == "weak"
+            and (args.width, args.height, args.path_length) == (1920, 1080, 4) and args.scaling == "weak" and args.shading_math == "exact"
         counters, counter_source = measured_counters(args.workload, "k_trace_%s<false>" % dominant) if profiled else (None, None)
         # What bounds the kernel, from what the hardware counted rather than from the byte model: the HBM traffic
         # of a launch against the 8 TB/s of the part, and the VALU wave instructions of a launch against what the
@@ -470,7 +475,7 @@ def run(args, image_out=None):
             "config": {"workload": "%s %dx%d, NEE + MIS, path length %d, %d frames per step (%s), frames %d.." % (
                            label, args.width, args.height, args.path_length, main_leg["frames_per_step"],
                            "%d per GPU" % spp if args.scaling == "weak" else "shared by all GPUs", spec.frame_index + 1),
-                       "lights": int(light_count), "light_sampling": args.light_sampling,
+                       "lights": int(light_count), "light_sampling": args.light_sampling, "shading_math": args.shading_math,
                        "spp_total": main_leg["steps"] * main_leg["frames_per_step"], "parallelism": backend.parallelism},
             "samples_per_s": total_paths / seconds,
             "rays_per_path": total_rays / total_paths,

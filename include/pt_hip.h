@@ -127,6 +127,21 @@ int pt_set_lights(pt_scene_t* scene, const float* lights, uint32_t count);
 enum { PT_LIGHT_SAMPLING_EXACT = 0, PT_LIGHT_SAMPLING_TREE = 1 };
 int pt_set_light_sampling(pt_scene_t* scene, int light_sampling);
 
+/* The arithmetic of the two loops over all lights in sample_lights()
+ * (src/shaders/pathtrace.frag.glsl:120-143) under sampling strategy 3 with
+ * PT_LIGHT_SAMPLING_EXACT. EXACT, the default, rounds the two divisions and
+ * the square root of get_spherical_light_importance() (:69-83) correctly, as
+ * IEEE arithmetic does, which makes images equal a CPU restatement of the
+ * shader bit for bit. FAST uses the GPU's approximate reciprocal and square
+ * root instructions (one unit in the last place), as a GPU's shader compiler
+ * is free to: random numbers, primary rays and their hits stay the same bits,
+ * radiance differs like a few more samples would change it (relative RMSE
+ * against EXACT at equal seeds below 2 % at 32 samples per pixel and falling
+ * with the sample count; image means within 0.1 %). The environment variable
+ * PT_SHADING_MATH=fast makes FAST the default of scenes created afterwards. */
+enum { PT_SHADING_MATH_EXACT = 0, PT_SHADING_MATH_FAST = 1 };
+int pt_set_shading_math(pt_scene_t* scene, int shading_math);
+
 /* Replaces the shader defines SAMPLING_STRATEGY_*, PATH_LENGTH and
  * EMISSION_MATERIAL_INDEX of src/main.c:936-949 (render_settings_t at
  * src/main.h:99-105). path_length is at most 16. */
@@ -190,6 +205,7 @@ uint32_t pt_context_device_count(const pt_context_t* context);
 pt_scene_t* pt_context_scene(pt_context_t* context, uint32_t index);
 int pt_context_set_lights(pt_context_t* context, const float* lights, uint32_t count);
 int pt_context_set_light_sampling(pt_context_t* context, int light_sampling);
+int pt_context_set_shading_math(pt_context_t* context, int shading_math);
 int pt_context_set_render_settings(pt_context_t* context, int sampling_strategy, uint32_t path_length, uint32_t emission_material_index);
 int pt_context_create_render_targets(pt_context_t* context, uint32_t width, uint32_t height);
 /* pt_render_samples() for sample_count frames in total, shared out as

@@ -506,7 +506,7 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(PtShad
 	PtLightCache light_cache;
 	light_cache.values = &pt_shade_light_importances[threadIdx.x];
 	light_cache.stride = PT_SHADE_BLOCK;
-	light_cache.capacity = (STRATEGY == PT_STRATEGY_NEE) ? a.light_cache_capacity : 0;
+	light_cache.capacity = (STRATEGY == PT_STRATEGY_NEE || STRATEGY == PT_STRATEGY_NEE_FAST) ? a.light_cache_capacity : 0;
 	uint32_t slot = first_slot + threadIdx.x;
 	bool active = slot < count;
 	uint32_t path = PT_INVALID;
@@ -747,6 +747,7 @@ struct pt_scene {
 	float light_grid_lo[3], light_grid_cell[3], light_grid_inv_cell[3], light_grid_reach;
 	uint32_t light_grid_dim[3];
 	int light_sampling;
+	int shading_math;
 	uint32_t light_count;
 	PtNode* nodes;
 	PtTri* tris;
@@ -1228,6 +1229,9 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 	s->srgb_to_linear = NULL; s->lights = NULL; s->light_count = 0; s->light_nodes = NULL; s->tree_lights = NULL; s->light_leaf_count = 0; s->light_grid_cells = NULL; s->light_grid_lights = NULL; s->light_grid_leaves = NULL; s->light_sampling = PT_LIGHT_SAMPLING_EXACT; s->nodes = NULL; s->tris = NULL;
 	memset(&s->bvh_info, 0, sizeof(s->bvh_info));
 	s->strategy = PT_STRATEGY_NEE;
+	// PT_SHADING_MATH=fast makes pt_set_shading_math(scene, PT_SHADING_MATH_FAST) the default of new scenes
+	const char* shading_math = getenv("PT_SHADING_MATH");
+	s->shading_math = (shading_math && strcmp(shading_math, "fast") == 0) ? PT_SHADING_MATH_FAST : PT_SHADING_MATH_EXACT;
 	s->path_length = 4;
 	s->emission_material_index = 0;
 	s->emissive_marks_valid = false;
@@ -1465,6 +1469,17 @@ extern "C" int pt_set_light_sampling(pt_scene_t* s, int light_sampling) {
 	return 0;
 }
 
+extern "C" int pt_set_shading_math(pt_scene_t* s, int shading_math) {
+	if (!s)
+		return 1;
+	if (shading_math != PT_SHADING_MATH_EXACT && shading_math != PT_SHADING_MATH_FAST) {
+		printf("Unsupported shading math mode %d.\n", shading_math);
+		return 1;
+	}
+	s->shading_math = shading_math;
+	return 0;
+}
+
 extern "C" int pt_set_render_settings(pt_scene_t* s, int sampling_strategy, uint32_t path_length, uint32_t emission_material_index) {
 	if (!s)
 		return 1;
@@ -1622,6 +1637,8 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 			default:
 				if (tree)
 					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE_TREE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a);
+				else if (s->shading_math == PT_SHADING_MATH_FAST)
+					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE_FAST>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a);
 				else
 					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a);
 				break;
@@ -2389,6 +2406,9 @@ extern "C" int pt_context_set_lights(pt_context_t* context, const float* lights,
 }
 extern "C" int pt_context_set_light_sampling(pt_context_t* context, int light_sampling) {
 	return pt_context_for_each(context, [&](pt_scene* s) { return pt_set_light_sampling(s, light_sampling); });
+}
+extern "C" int pt_context_set_shading_math(pt_context_t* context, int shading_math) {
+	return pt_context_for_each(context, [&](pt_scene* s) { return pt_set_shading_math(s, shading_math); });
 }
 extern "C" int pt_context_set_render_settings(pt_context_t* context, int sampling_strategy, uint32_t path_length, uint32_t emission_material_index) {
 	return pt_context_for_each(context, [&](pt_scene* s) { return pt_set_render_settings(s, sampling_strategy, path_length, emission_material_index); });

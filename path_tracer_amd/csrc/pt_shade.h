@@ -622,6 +622,25 @@ PT_FN float pt_spherical_light_importance(f32x4 light, v3 shading_pos, v3 normal
 	return sin_2 / (1.0f + pt_sqrt_at_least_2_pow_minus_96(fmaxf(0.0f, 1.0f - sin_2)));
 }
 
+// The same with the hardware's reciprocal and square root, each good to one
+// unit in the last place, instead of two correctly rounded divisions and a
+// correctly rounded root: a third of the instructions. The value differs from
+// pt_spherical_light_importance() in the last bits, so an image differs from
+// the exact one like two images with different seeds do, only far less.
+PT_FN float pt_spherical_light_importance_fast(f32x4 light, v3 shading_pos, v3 normal) {
+	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
+	if (dot(normal, center_dir) < -light.w)
+		return 0.0f;
+	float center_dist_2 = dot(center_dir, center_dir);
+#if defined(__HIP_DEVICE_COMPILE__)
+	float sin_2 = (light.w * light.w) * __builtin_amdgcn_rcpf(center_dist_2);
+	return sin_2 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - sin_2)));
+#else
+	float sin_2 = light.w * light.w / center_dist_2;
+	return sin_2 / (1.0f + sqrtf(fmaxf(0.0f, 1.0f - sin_2)));
+#endif
+}
+
 // ---- pathtrace.frag.glsl:95-106 ----
 PT_FN v3 pt_sample_spherical_light(f32x4 light, float importance, v3 shading_pos, v2 randoms) {
 	float azimuth = (2.0f * PT_PI) * randoms.x - PT_PI;
@@ -643,11 +662,11 @@ struct PtLightCache {
 };
 
 // ---- pathtrace.frag.glsl:120-143 ----
-PT_FN v3 pt_sample_lights(const PtSceneView& scene, const PtLightCache& cache, float* out_total_importance, v3 shading_pos, v3 normal, v2 randoms) {
+PT_FN v3 pt_sample_lights(const PtSceneView& scene, const PtLightCache& cache, float* out_total_importance, v3 shading_pos, v3 normal, v2 randoms, bool fast = false) {
 	float total = 0.0f;
 	PT_LIGHT_LOOP_UNROLL
 	for (uint32_t i = 0; i != scene.light_count; ++i) {
-		float importance = pt_spherical_light_importance(pt_light(scene, i), shading_pos, normal);
+		float importance = fast ? pt_spherical_light_importance_fast(pt_light(scene, i), shading_pos, normal) : pt_spherical_light_importance(pt_light(scene, i), shading_pos, normal);
 		if (i < cache.capacity)
 			cache.values[i * cache.stride] = importance;
 		total += importance;
@@ -657,7 +676,8 @@ PT_FN v3 pt_sample_lights(const PtSceneView& scene, const PtLightCache& cache, f
 	float prefix_importance = 0.0f;
 	for (uint32_t i = 0; i != scene.light_count; ++i) {
 		f32x4 light = pt_light(scene, i);
-		float importance = (i < cache.capacity) ? cache.values[i * cache.stride] : pt_spherical_light_importance(light, shading_pos, normal);
+		float importance = (i < cache.capacity) ? cache.values[i * cache.stride]
+			: (fast ? pt_spherical_light_importance_fast(light, shading_pos, normal) : pt_spherical_light_importance(light, shading_pos, normal));
 		prefix_importance += importance;
 		if (prefix_importance > target_importance) {
 			randoms.x = ((target_importance + importance) - prefix_importance) / importance;
@@ -1127,7 +1147,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 	r.next_cone = 0.0f;
 	// In the NEE estimator emission is weighted by nee_throughput, in the
 	// others by throughput (pathtrace.frag.glsl:231,265,293,323)
-	bool next_event_estimation = strategy == PT_STRATEGY_NEE || strategy == PT_STRATEGY_NEE_TREE;
+	bool next_event_estimation = strategy == PT_STRATEGY_NEE || strategy == PT_STRATEGY_NEE_TREE || strategy == PT_STRATEGY_NEE_FAST;
 	v3 emission_weight = next_event_estimation ? nee_throughput : throughput;
 	if (hit_prim == 0xffffffffu) {
 		emitted = emission_weight * mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
@@ -1180,7 +1200,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		tree_sample.probability = 0.0f;
 		v3 light_dir = (strategy == PT_STRATEGY_NEE_TREE)
 			? pt_sample_lights_tree(scene, &sampled_light_density, &tree_sample, s.pos, s.normal, pt_random(sx, sy))
-			: pt_sample_lights(scene, light_cache, &total_light_importance, s.pos, s.normal, pt_random(sx, sy));
+			: pt_sample_lights(scene, light_cache, &total_light_importance, s.pos, s.normal, pt_random(sx, sy), strategy == PT_STRATEGY_NEE_FAST);
 		float lambert_in_0 = dot(s.normal, light_dir);
 		r.next_dir = pt_sample_frostbite_brdf(s, pt_random(sx, sy));
 		float lambert_in_1 = dot(s.normal, r.next_dir);

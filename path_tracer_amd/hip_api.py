@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpt_hip.so")
 
 SAMPLING_STRATEGY_SPHERICAL, SAMPLING_STRATEGY_PSA, SAMPLING_STRATEGY_BRDF, SAMPLING_STRATEGY_NEE = range(4)
 LIGHT_SAMPLING_EXACT, LIGHT_SAMPLING_TREE = range(2)
+SHADING_MATH_EXACT, SHADING_MATH_FAST = range(2)
 
 EXPORTED_SYMBOLS = [
     "pt_create_scene", "pt_destroy_scene", "pt_set_lights", "pt_set_light_sampling", "pt_set_render_settings", "pt_create_render_targets",
@@ -23,6 +24,7 @@ EXPORTED_SYMBOLS = [
     "pt_context_render_samples", "pt_context_synchronize", "pt_context_reduce", "pt_context_last_reduce_ms",
     "pt_trace_primary_rays", "pt_trace_rays", "pt_trace_rays_no_alloc", "pt_evaluate_shading_data", "pt_random_numbers",
     "pt_abi_version", "pt_get_device_count", "pt_context_frame_slice", "pt_evaluate_function",
+    "pt_set_shading_math", "pt_context_set_shading_math",
 ]
 ABI_VERSION = 3  # PT_HIP_ABI_VERSION of the include/pt_hip.h that the structures below mirror
 
@@ -94,6 +96,8 @@ def lib():
         _lib.pt_set_lights.argtypes = [vp, vp, u32]
         _lib.pt_set_light_sampling.argtypes = [vp, i32]
         _lib.pt_set_render_settings.argtypes = [vp, i32, u32, u32]
+        _lib.pt_set_shading_math.argtypes = [vp, i32]
+        _lib.pt_context_set_shading_math.argtypes = [vp, i32]
         _lib.pt_create_render_targets.argtypes = [vp, u32, u32]
         _lib.pt_render_samples.argtypes = [vp, C.POINTER(Constants), u32, u32, u32, i32]
         _lib.pt_synchronize.argtypes = [vp]
@@ -189,6 +193,9 @@ class Scene:
 
     def set_light_sampling(self, light_sampling):
         _check(lib().pt_set_light_sampling(self.handle, light_sampling), "pt_set_light_sampling")
+
+    def set_shading_math(self, shading_math):
+        _check(lib().pt_set_shading_math(self.handle, shading_math), "pt_set_shading_math")
 
     def set_render_settings(self, sampling_strategy=SAMPLING_STRATEGY_NEE, path_length=4, emission_material_index=0):
         _check(lib().pt_set_render_settings(self.handle, sampling_strategy, path_length, emission_material_index), "pt_set_render_settings")

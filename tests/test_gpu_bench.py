@@ -80,3 +80,42 @@ def test_accumulating_into_an_empty_target_takes_the_discard_pipeline():
     again, count = renderer.read_accumulation()
     assert count == 3 and (bits(again) == bits(fresh)).all()
     renderer.close()
+
+
+def test_fast_shading_math_stays_within_its_tolerance():
+    """pt_set_shading_math(PT_SHADING_MATH_FAST): approximate reciprocals and square roots in the loops over all
+    lights. Primary hits are the same bits (they do not depend on it); radiance at equal seeds differs from the exact
+    mode by a relative RMSE below 2 % at 32 samples per pixel, less with more samples, and image means agree within
+    0.1 %. Most pixels do not change at all: a difference arises where the last bits of an importance move a sample
+    across the boundary between two lights."""
+    from tests import synthetic
+    import oracle
+    from tests.test_gpu_parity import gpu_scene, to_gpu_constants
+    scene, lights = synthetic.lit_room(seed=5, light_count=28)
+    width, height = 256, 144
+    constants = to_gpu_constants(oracle.write_constants(synthetic.look_at_spec((4.0, -5.0, 2.5), (1.3, 0.0, 0.7), emission_strength=30.0), width, height, scene, lights))
+    library = gpu_scene(scene, lights)
+    library.create_render_targets(width, height)
+    library.set_render_settings(3, 4, scene.emission_material_index)
+    images = {}
+    for spp in (32, 512):
+        for mode in (hip_api.SHADING_MATH_EXACT, hip_api.SHADING_MATH_FAST):
+            library.set_shading_math(mode)
+            library.render_samples(constants, 900, spp, 1, accumulate=False)
+            image, count = library.read_accumulation()
+            images[spp, mode] = image[..., :3].astype(np.float64) / count
+            hits = library.trace_primary_rays(constants, 900)
+            if mode == hip_api.SHADING_MATH_EXACT:
+                exact_hits = hits
+            else:
+                assert all((a == b).all() for a, b in zip(hits, exact_hits))
+    errors = {}
+    for spp in (32, 512):
+        exact, fast = images[spp, hip_api.SHADING_MATH_EXACT], images[spp, hip_api.SHADING_MATH_FAST]
+        assert np.isfinite(fast).all() and exact.mean() > 0.01
+        errors[spp] = np.sqrt(((fast - exact) ** 2).mean()) / exact.mean()
+        assert abs(fast.mean() - exact.mean()) < 1e-3 * exact.mean(), (spp, fast.mean(), exact.mean())
+        assert (fast != exact).any(axis=2).mean() < 0.5
+    assert errors[32] < 0.02 and errors[512] < 0.01, errors
+    library.set_shading_math(hip_api.SHADING_MATH_EXACT)
+    library.close()

@@ -272,7 +272,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	// EMISSIVE_ONLY: bit 0: the closest hit so far is not emissive; bit 1:
 	// something was skipped on that account; bit 2: this is the second walk
 	uint32_t emissive_state = 0;
-	uint32_t node_visits = 0, tri_visits = 0, lds_node_visits = 0, lds_tri_visits = 0;
+	uint32_t node_visits = 0, tri_visits = 0, lds_node_visits = 0, lds_tri_visits = 0, empty_node_visits = 0;
 	uint32_t pass_count = 0, refill_count = 0, node_pass_count = 0, tri_pass_count = 0;
 	(void) node_pass_count; (void) tri_pass_count;
 	unsigned long long active_lane_passes = 0;
@@ -473,6 +473,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					missed8 = __builtin_amdgcn_alignbit(missed8, pt_as_uint(tf - tn), 31);
 				}
 				uint32_t hit8 = ~missed8 & 0xffu;
+				if (COUNT_VISITS)
+					empty_node_visits += ((hit8 & (imask | leafmask)) == 0u) ? 1u : 0u;
 				if (EMISSIVE_ONLY && (emissive_state & 1u)) {
 					uint32_t marked = hit8 & (w1.z >> 8);
 					emissive_state |= (marked != hit8) ? 2u : 0u;
@@ -564,6 +566,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		atomicAdd(&visit_counters[1], (unsigned long long) tri_visits);
 		atomicAdd(&visit_counters[20], (unsigned long long) lds_node_visits);
 		atomicAdd(&visit_counters[21], (unsigned long long) lds_tri_visits);
+		atomicAdd(&visit_counters[12], (unsigned long long) empty_node_visits);
 		if (lane == 0) {
 			// Diagnostics: passes, lanes active in them, refills (summed over waves)
 			atomicAdd(&visit_counters[6], (unsigned long long) pass_count);

@@ -84,6 +84,19 @@ KERNEL(k_add_co, "v_add_co_u32 %0, vcc, %1, %0")
 KERNEL(k_fma_abs, "v_fma_f32 %0, |%1|, %2, %0")
 KERNEL(k_mul_e64, "v_mul_f32_e64 %0, |%1|, %0")
 
+// Packed half precision: two results per lane and instruction
+KERNEL(k_pk_fma_f16, "v_pk_fma_f16 %0, %1, %2, %0")
+KERNEL(k_pk_mul_f16, "v_pk_mul_f16 %0, %1, %0")
+KERNEL(k_pk_add_f16, "v_pk_add_f16 %0, %1, %0")
+KERNEL(k_pk_max_f16, "v_pk_max_f16 %0, %1, %0")
+KERNEL(k_pk_min_f16, "v_pk_min_f16 %0, %1, %0")
+KERNEL(k_cvt_pkrtz, "v_cvt_pkrtz_f16_f32 %0, %1, %0")
+KERNEL(k_fma_f16, "v_fma_f16 %0, %1, %2, %0")
+KERNEL(k_pk_max_i16, "v_pk_max_i16 %0, %1, %0")
+KERNEL(k_pk_sub_i16, "v_pk_sub_i16 %0, %1, %0")
+KERNEL(k_pk_mad_i16, "v_pk_mad_i16 %0, %1, %2, %0")
+KERNEL(k_pk_lshlrev_b16, "v_pk_lshlrev_b16 %0, 3, %0")
+
 // Two different instructions in turn (16 of each per 32): do their costs add, or do they run on different pipes?
 #define OP8_MIXED(text_a, text_b) \
 	asm volatile(text_a : "+v"(a0) : "v"(b), "v"(c) : "vcc", "s10", "s11"); asm volatile(text_b : "+v"(a1) : "v"(b), "v"(c) : "vcc", "s10", "s11"); \
@@ -104,6 +117,40 @@ KERNEL_MIXED(k_mix_fma_rcp, "v_fma_f32 %0, %1, %2, %0", "v_rcp_f32 %0, %0")
 KERNEL_MIXED(k_mix_max3_rcp, "v_max3_f32 %0, %1, %2, %0", "v_rcp_f32 %0, %0")
 KERNEL_MIXED(k_mix_fma_add, "v_fma_f32 %0, %1, %2, %0", "v_add_f32 %0, %1, %0")
 KERNEL_MIXED(k_mix_fma_and, "v_fma_f32 %0, %1, %2, %0", "v_and_b32 %0, %1, %0")
+KERNEL_MIXED(k_mix_pkfma16_perm, "v_pk_fma_f16 %0, %1, %2, %0", "v_perm_b32 %0, %1, %2, %0")
+KERNEL_MIXED(k_mix_pkfma16_pkmax16, "v_pk_fma_f16 %0, %1, %2, %0", "v_pk_max_f16 %0, %1, %0")
+KERNEL_MIXED(k_mix_pkfma16_and, "v_pk_fma_f16 %0, %1, %2, %0", "v_and_b32 %0, %1, %0")
+KERNEL_MIXED(k_mix_pkmax16_pkmin16, "v_pk_max_f16 %0, %1, %0", "v_pk_min_f16 %0, %1, %0")
+
+// Streams of two-cycle and four-cycle instructions in other proportions (eight per group, then repeated)
+#define OP8_PATTERN(t0, t1, t2, t3, t4, t5, t6, t7) \
+	asm volatile(t0 : "+v"(a0) : "v"(b), "v"(c) : "vcc", "s10", "s11"); asm volatile(t1 : "+v"(a1) : "v"(b), "v"(c) : "vcc", "s10", "s11"); \
+	asm volatile(t2 : "+v"(a2) : "v"(b), "v"(c) : "vcc", "s10", "s11"); asm volatile(t3 : "+v"(a3) : "v"(b), "v"(c) : "vcc", "s10", "s11"); \
+	asm volatile(t4 : "+v"(a4) : "v"(b), "v"(c) : "vcc", "s10", "s11"); asm volatile(t5 : "+v"(a5) : "v"(b), "v"(c) : "vcc", "s10", "s11"); \
+	asm volatile(t6 : "+v"(a6) : "v"(b), "v"(c) : "vcc", "s10", "s11"); asm volatile(t7 : "+v"(a7) : "v"(b), "v"(c) : "vcc", "s10", "s11");
+#define KERNEL_PATTERN(name, t0, t1, t2, t3, t4, t5, t6, t7) \
+__global__ void __launch_bounds__(1024, 8) name(float* out, int iterations, float b, float c) { \
+	float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+	for (int i = 0; i != iterations; ++i) { OP8_PATTERN(t0, t1, t2, t3, t4, t5, t6, t7) OP8_PATTERN(t0, t1, t2, t3, t4, t5, t6, t7) OP8_PATTERN(t0, t1, t2, t3, t4, t5, t6, t7) OP8_PATTERN(t0, t1, t2, t3, t4, t5, t6, t7) } \
+	out[blockIdx.x * 1024 + threadIdx.x] = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7)); \
+}
+#define FAST_OP "v_fma_f32 %0, %1, %2, %0"
+#define FAST_OP_2 "v_sub_f32 %0, %1, %0"
+#define SLOW_OP "v_cvt_f32_ubyte0 %0, %1"
+#define SLOW_OP_2 "v_max3_f32 %0, %1, %2, %0"
+KERNEL_PATTERN(k_mix_5fast_3slow, FAST_OP, SLOW_OP, FAST_OP_2, FAST_OP, SLOW_OP_2, FAST_OP, SLOW_OP, FAST_OP_2)
+KERNEL_PATTERN(k_mix_6fast_2slow, FAST_OP, SLOW_OP, FAST_OP_2, FAST_OP, FAST_OP, FAST_OP_2, SLOW_OP_2, FAST_OP)
+KERNEL_PATTERN(k_mix_7fast_1slow, FAST_OP, FAST_OP_2, FAST_OP, SLOW_OP, FAST_OP, FAST_OP_2, FAST_OP, FAST_OP)
+KERNEL_PATTERN(k_mix_3fast_5slow, SLOW_OP, FAST_OP, SLOW_OP_2, SLOW_OP, FAST_OP_2, SLOW_OP_2, FAST_OP, SLOW_OP)
+KERNEL_PATTERN(k_mix_2fast_6slow, SLOW_OP, FAST_OP, SLOW_OP_2, SLOW_OP, SLOW_OP, SLOW_OP_2, FAST_OP_2, SLOW_OP)
+KERNEL_PATTERN(k_mix_4fast_4slow_runs, FAST_OP, FAST_OP_2, FAST_OP, FAST_OP_2, SLOW_OP, SLOW_OP_2, SLOW_OP, SLOW_OP_2)
+KERNEL(k_cndmask_e64_vcc, "v_cndmask_b32_e64 %0, %1, %0, vcc")
+// Fused multiply-add with a half-precision operand converted on the fly
+#define FMA_MIX "v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]"
+KERNEL(k_fma_mix, FMA_MIX)
+KERNEL_PATTERN(k_mix_2fmamix_1perm, FMA_MIX, FMA_MIX, "v_perm_b32 %0, %1, %2, %0", FMA_MIX, FMA_MIX, "v_perm_b32 %0, %1, %2, %0", FAST_OP_2, SLOW_OP_2)
+KERNEL_PATTERN(k_mix_fmamix_max3, FMA_MIX, SLOW_OP_2, FMA_MIX, SLOW_OP_2, FMA_MIX, SLOW_OP_2, FMA_MIX, SLOW_OP_2)
+KERNEL_PATTERN(k_mix_fmamix_sub, FMA_MIX, FAST_OP_2, FMA_MIX, FAST_OP_2, FMA_MIX, FAST_OP_2, FMA_MIX, FAST_OP_2)
 
 // Packed single precision: two results per lane and instruction
 #define OP8P(text) \
@@ -147,6 +194,10 @@ int main() {
 		CASE(k_not), CASE(k_max_u32), CASE(k_cvt_i32_f32), CASE(k_floor), CASE(k_fract), CASE(k_add_f32_e64_neg), CASE(k_ldexp), CASE(k_exp), CASE(k_log), CASE(k_sin), CASE(k_add_co),
 		CASE(k_mix_fma_cndmask), CASE(k_mix_fma_cvt), CASE(k_mix_fma_max3), CASE(k_mix_cndmask_cvt), CASE(k_mix_fma_rcp), CASE(k_mix_max3_rcp), CASE(k_mix_fma_add), CASE(k_mix_fma_and),
 		CASE(k_fma_abs), CASE(k_mul_e64), CASE(k_pk_fma), CASE(k_pk_mul), CASE(k_pk_add),
+		CASE(k_pk_fma_f16), CASE(k_pk_mul_f16), CASE(k_pk_add_f16), CASE(k_pk_max_f16), CASE(k_pk_min_f16), CASE(k_cvt_pkrtz), CASE(k_fma_f16),
+		CASE(k_pk_max_i16), CASE(k_pk_sub_i16), CASE(k_pk_mad_i16), CASE(k_pk_lshlrev_b16),
+		CASE(k_mix_7fast_1slow), CASE(k_mix_6fast_2slow), CASE(k_mix_5fast_3slow), CASE(k_mix_4fast_4slow_runs), CASE(k_mix_3fast_5slow), CASE(k_mix_2fast_6slow), CASE(k_cndmask_e64_vcc), CASE(k_fma_mix), CASE(k_mix_2fmamix_1perm), CASE(k_mix_fmamix_max3), CASE(k_mix_fmamix_sub),
+		CASE(k_mix_pkfma16_perm), CASE(k_mix_pkfma16_pkmax16), CASE(k_mix_pkfma16_and), CASE(k_mix_pkmax16_pkmin16),
 	};
 	printf("%d CUs, %d MHz nominal; cycles are SIMD cycles per wave64 instruction with 8 waves per SIMD at the nominal clock\n", cu_count, clock_khz / 1000);
 	for (auto& c : cases) {

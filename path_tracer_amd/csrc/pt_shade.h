@@ -375,6 +375,13 @@ PT_FN float pt_cone_spread_after_bounce(float spread, float density) {
 }
 
 
+#ifndef PT_TEXTURE_TAPS
+// Texture lookups take one trilinear tap. A value above one builds the
+// measurement variant with an anisotropic filter of up to that many taps
+// (see pt_shading_data()), against which the one-tap rule is compared.
+#define PT_TEXTURE_TAPS 1
+#endif
+
 // ---- shading_data.glsl:19-39 ----
 struct PtShadingData {
 	v3 pos, normal, out_dir;
@@ -423,6 +430,45 @@ PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants&
 	v3 face = cross(poss[1] - poss[0], poss[2] - poss[0]);
 	s.footprint = fmaf(cone_spread, pt_length(s.pos - cone_origin), cone_width);
 	float lod_base = pt_texture_lod_base(fabsf(e1.x * e2.y - e2.x * e1.y), pt_length(face), s.footprint, fabsf(dot(normal_geo, out_dir)));
+#if PT_TEXTURE_TAPS > 1
+	// Measurement variant (never the product's default): an anisotropic filter as
+	// a sampler with maxAnisotropy = PT_TEXTURE_TAPS takes it (src/main.c:864-873),
+	// N = min(ceil(1 / cos), PT_TEXTURE_TAPS) trilinear taps spread evenly along the
+	// major axis of the footprint's ellipse on the surface, the projection of the
+	// ray onto the triangle's plane, each at the level of detail of the minor axis
+	v3 base_color = mk3(0.0f, 0.0f, 0.0f), specular = mk3(0.0f, 0.0f, 0.0f), normal_tex = mk3(0.0f, 0.0f, 0.0f);
+	{
+		float cos_out = fmaxf(fabsf(dot(normal_geo, out_dir)), 1.0e-4f);
+		float stretch = fminf(1.0f / cos_out, (float) PT_TEXTURE_TAPS);
+		int taps = (int) ceilf(stretch);
+		v3 along = out_dir - normal_geo * dot(normal_geo, out_dir);
+		float along_length = pt_length(along);
+		v3 major = (along_length > 1.0e-6f) ? along * (1.0f / along_length) : mk3(0.0f, 0.0f, 0.0f);
+		// A step along the surface in texture coordinates: major = a * edge_1 + b * edge_2 (least squares)
+		v3 edge_1 = poss[1] - poss[0], edge_2 = poss[2] - poss[0];
+		float g11 = dot(edge_1, edge_1), g12 = dot(edge_1, edge_2), g22 = dot(edge_2, edge_2);
+		float determinant = g11 * g22 - g12 * g12;
+		float r1 = dot(major, edge_1), r2 = dot(major, edge_2);
+		float a = 0.0f, b = 0.0f;
+		if (determinant > 0.0f) {
+			a = (r1 * g22 - r2 * g12) / determinant;
+			b = (r2 * g11 - r1 * g12) / determinant;
+		}
+		v2 uv_step = mk2(a * e1.x + b * e2.x, a * e1.y + b * e2.y);
+		float half_length = 0.5f * s.footprint * stretch;
+		for (int tap = 0; tap != taps; ++tap) {
+			float offset = half_length * ((2.0f * ((float) tap + 0.5f)) / (float) taps - 1.0f);
+			v2 tap_tc = mk2(tc.x + offset * uv_step.x, tc.y + offset * uv_step.y);
+			base_color = base_color + pt_sample_texture(scene, 3 * material + 0, tap_tc, lod_base);
+			specular = specular + pt_sample_texture(scene, 3 * material + 1, tap_tc, lod_base);
+			normal_tex = normal_tex + pt_sample_texture(scene, 3 * material + 2, tap_tc, lod_base);
+		}
+		float weight = 1.0f / (float) taps;
+		base_color = base_color * weight;
+		specular = specular * weight;
+		normal_tex = normal_tex * weight;
+	}
+#else
 	// All texels of the three lookups are requested before the first is used
 	PtTextureLookup base_color_lookup = pt_begin_texture_lookup(scene, 3 * material + 0, tc, lod_base);
 	PtTextureLookup specular_lookup = pt_begin_texture_lookup(scene, 3 * material + 1, tc, lod_base);
@@ -430,6 +476,7 @@ PT_FN PtShadingData pt_shading_data(const PtSceneView& scene, const PtConstants&
 	v3 base_color = pt_finish_texture_lookup(scene, base_color_lookup);
 	v3 specular = pt_finish_texture_lookup(scene, specular_lookup);
 	v3 normal_tex = pt_finish_texture_lookup(scene, normal_lookup);
+#endif
 	v3 normal_local;
 	normal_local.x = normal_tex.x * 2.0f - 1.0f;
 	normal_local.y = normal_tex.y * 2.0f - 1.0f;

@@ -282,8 +282,10 @@ int pt_trace_rays(pt_scene_t* scene, const float* origins, const float* directio
 	int32_t* triangle_indices, float* t_u_v, uint8_t* front);
 
 /* pt_trace_rays() without any allocation. It has no counterpart in the
- * reference; it is for callers that cannot allocate device memory: code under
- * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * reference; it is for callers that cannot allocate device memory: tight
+ * serving loops, harnesses that forbid hipMalloc. (It is not a call to record
+ * into a HIP graph: it launches on the library's own stream, waits for it and
+ * reads the library's error word back.)
  * All five arrays are device memory of the caller on the scene's GPU
  * (origins and directions three floats per ray, results as pt_trace_rays()
  * returns them). The ray queue and its counters live in an array that is

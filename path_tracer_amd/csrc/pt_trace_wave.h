@@ -272,7 +272,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	// EMISSIVE_ONLY: bit 0: the closest hit so far is not emissive; bit 1:
 	// something was skipped on that account; bit 2: this is the second walk
 	uint32_t emissive_state = 0;
-	uint32_t node_visits = 0, tri_visits = 0, lds_node_visits = 0, lds_tri_visits = 0, empty_node_visits = 0;
+	uint32_t node_visits = 0, tri_visits = 0, lds_node_visits = 0, lds_tri_visits = 0, empty_node_visits = 0, culled_by_hit_visits = 0;
 	uint32_t pass_count = 0, refill_count = 0, node_pass_count = 0, tri_pass_count = 0;
 	(void) node_pass_count; (void) tri_pass_count;
 	unsigned long long active_lane_passes = 0;
@@ -473,8 +473,24 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					missed8 = __builtin_amdgcn_alignbit(missed8, pt_as_uint(tf - tn), 31);
 				}
 				uint32_t hit8 = ~missed8 & 0xffu;
-				if (COUNT_VISITS)
-					empty_node_visits += ((hit8 & (imask | leafmask)) == 0u) ? 1u : 0u;
+				if (COUNT_VISITS) {
+					// Node steps that found nothing, and among them those that would have found
+					// something without the closest hit so far (the node was put on the stack
+					// before that hit was known)
+					bool empty = (hit8 & (imask | leafmask)) == 0u;
+					empty_node_visits += empty ? 1u : 0u;
+					uint32_t missed8_unbounded = 0;
+#pragma unroll
+					for (int i = 7; i >= 0; --i) {
+						float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bxn), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bxf);
+						float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, byn), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, byf);
+						float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bzn), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bzf);
+						float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+						float tf = fminf(fminf(fx, fy), fz);
+						missed8_unbounded = __builtin_amdgcn_alignbit(missed8_unbounded, pt_as_uint(tf - tn), 31);
+					}
+					culled_by_hit_visits += (empty && (~missed8_unbounded & (imask | leafmask) & 0xffu) != 0u) ? 1u : 0u;
+				}
 				if (EMISSIVE_ONLY && (emissive_state & 1u)) {
 					uint32_t marked = hit8 & (w1.z >> 8);
 					emissive_state |= (marked != hit8) ? 2u : 0u;
@@ -567,6 +583,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		atomicAdd(&visit_counters[20], (unsigned long long) lds_node_visits);
 		atomicAdd(&visit_counters[21], (unsigned long long) lds_tri_visits);
 		atomicAdd(&visit_counters[12], (unsigned long long) empty_node_visits);
+		atomicAdd(&visit_counters[13], (unsigned long long) culled_by_hit_visits);
 		if (lane == 0) {
 			// Diagnostics: passes, lanes active in them, refills (summed over waves)
 			atomicAdd(&visit_counters[6], (unsigned long long) pass_count);

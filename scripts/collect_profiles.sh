@@ -1,9 +1,9 @@
 #!/bin/bash
 # Copies the profiling results of scripts/gpu_profile.sh and scripts/gpu_pmc.sh runs tagged cornell_<tag> and city_<tag>
-# from gpurun_out/ into profiles/<round>/<tag>/ and rebuilds profiles/pmc_current.json. usage: scripts/collect_profiles.sh <tag> [round, default r2]
+# from gpurun_out/ into profiles/<round>/<tag>/ and rebuilds profiles/pmc_current.json. usage: scripts/collect_profiles.sh <tag> [round, default r3]
 set -e
 tag=$1
-round=${2:-r2}
+round=${2:-r3}
 dst=profiles/$round/$tag
 mkdir -p $dst
 for w in cornell city; do
@@ -14,5 +14,5 @@ for w in cornell city; do
 done
 rm -f profiles/pmc_current.json
 for w in cornell city; do
-	python3 scripts/pmc_to_json.py $dst/pmc_${w}_summary.txt $w profiles/pmc_current.json > /dev/null
+	python3 scripts/pmc_to_json.py $dst/pmc_${w}_summary.txt $w profiles/pmc_current.json $dst/kernel_stats_$w.csv > /dev/null
 done

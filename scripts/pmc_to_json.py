@@ -1,6 +1,9 @@
 """Turns the per-kernel counter summary of scripts/gpu_pmc.sh into the JSON that bench.py reads for roofline.traffic.
 
-usage: pmc_to_json.py gpurun_out/pmc_<tag>/summary.txt <workload> profiles/pmc_current.json
+usage: pmc_to_json.py gpurun_out/pmc_<tag>/summary.txt <workload> profiles/pmc_current.json [kernel_stats.csv]
+With the kernel statistics of a `rocprofv3 --kernel-trace --stats` run of the same command on the same box, every
+kernel also gets kernel_trace_avg_ms, its average duration there: bench.py prints it as roofline.counter_run_ms beside
+the live avg_launch_ms, which shows how far the box of the counter passes and the box of a run are apart.
 FETCH_SIZE and WRITE_SIZE are KiB per launch; on gfx950 FETCH_SIZE counts 64 bytes per 128-byte request, so it is
 doubled (MI355X guide, section HBM). VALU busy = wave-level VALU instructions x 4 cycles / (SIMDs x kernel cycles) is
 not in the file because rocprofv3 reports no duration in counter mode.
@@ -11,6 +14,11 @@ import os
 import sys
 
 summary, workload, target = sys.argv[1:4]
+durations = {}
+if len(sys.argv) > 4:
+    import csv
+    for row in csv.DictReader(open(sys.argv[4])):
+        durations[row["Name"].split("(")[0].replace("void ", "")] = float(row["AverageNs"]) * 1e-6
 counters = collections.defaultdict(dict)
 for line in open(summary):
     parts = line.strip().rsplit(",", 4)  # kernel names with two template arguments contain a comma
@@ -40,6 +48,8 @@ for kernel, c in counters.items():
             entry["l1_read_requests_to_l2_per_launch"] = c["TCP_TCC_READ_REQ_sum"]
             entry["l2_read_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"]
             entry["l1_read_requests_per_cycle_and_cu"] = c["TCP_TCC_READ_REQ_sum"] / 256.0 / cycles
+    if kernel in durations:
+        entry["kernel_trace_avg_ms"] = durations[kernel]
     result[kernel] = entry
 existing = json.load(open(target)) if os.path.exists(target) else {}
 existing[workload] = {"source": summary, "kernels": result}

@@ -83,11 +83,11 @@ def test_accumulating_into_an_empty_target_takes_the_discard_pipeline():
 
 
 def test_fast_shading_math_stays_within_its_tolerance():
-    """pt_set_shading_math(PT_SHADING_MATH_FAST): approximate reciprocals and square roots in the loops over all
-    lights. Primary hits are the same bits (they do not depend on it); radiance at equal seeds differs from the exact
-    mode by a relative RMSE below 2 % at 32 samples per pixel, less with more samples, and image means agree within
-    0.1 %. Most pixels do not change at all: a difference arises where the last bits of an importance move a sample
-    across the boundary between two lights."""
+    """pt_set_shading_math(PT_SHADING_MATH_FAST): the shading kernel with fused multiply-adds, approximate division
+    and square root, and bare reciprocals in the loops over all lights. Primary hits are the same bits (they do not
+    depend on it); radiance at equal seeds differs from the exact mode in the last bits nearly everywhere, and by more
+    where such a difference moves a sample across the boundary between two lights or two triangles: relative RMSE
+    below 2 % at 32 samples per pixel, below 1 % at 512, image means within 0.1 %."""
     from tests import synthetic
     import oracle
     from tests.test_gpu_parity import gpu_scene, to_gpu_constants
@@ -115,7 +115,7 @@ def test_fast_shading_math_stays_within_its_tolerance():
         assert np.isfinite(fast).all() and exact.mean() > 0.01
         errors[spp] = np.sqrt(((fast - exact) ** 2).mean()) / exact.mean()
         assert abs(fast.mean() - exact.mean()) < 1e-3 * exact.mean(), (spp, fast.mean(), exact.mean())
-        assert (fast != exact).any(axis=2).mean() < 0.5
+    print("relative RMSE of fast against exact shading math:", errors)
     assert errors[32] < 0.02 and errors[512] < 0.01, errors
     library.set_shading_math(hip_api.SHADING_MATH_EXACT)
     library.close()

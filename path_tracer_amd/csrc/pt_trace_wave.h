@@ -32,7 +32,7 @@
 
 #define PT_TRACE_BLOCK 1024   // threads per workgroup of the traversal kernels
 #define PT_WAVES_PER_BLOCK 16
-#define PT_VISIT_COUNTERS 24 // 64-bit words of visit counters and diagnostics
+#define PT_VISIT_COUNTERS 32 // 64-bit words of visit counters and diagnostics
 #ifndef PT_TRACE_BLOCKS_PER_CU
 #define PT_TRACE_BLOCKS_PER_CU 2 // workgroups that share a CU and its LDS: 32 waves, the most a CU holds
 #endif
@@ -272,7 +272,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	// EMISSIVE_ONLY: bit 0: the closest hit so far is not emissive; bit 1:
 	// something was skipped on that account; bit 2: this is the second walk
 	uint32_t emissive_state = 0;
-	uint32_t node_visits = 0, tri_visits = 0, lds_node_visits = 0, lds_tri_visits = 0, empty_node_visits = 0, culled_by_hit_visits = 0;
+	uint32_t node_visits = 0, tri_visits = 0, lds_node_visits = 0, lds_tri_visits = 0, empty_node_visits = 0, culled_by_hit_visits = 0, distinct_node_fetches = 0;
 	uint32_t pass_count = 0, refill_count = 0, node_pass_count = 0, tri_pass_count = 0;
 	(void) node_pass_count; (void) tri_pass_count;
 	unsigned long long active_lane_passes = 0;
@@ -429,6 +429,14 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 				if (COUNT_VISITS) {
 					++node_visits;
 					lds_node_visits += (node_index < layout.node_count) ? 1u : 0u;
+					// How many different nodes the lanes of this pass fetch: what a walk
+					// that shared the fetch and the stack among the lanes would visit
+					unsigned long long todo = __ballot(true);
+					while (todo) {
+						uint32_t first = (uint32_t) __builtin_amdgcn_readlane((int) node_index, (int) __builtin_ctzll(todo));
+						todo &= ~__ballot(node_index == first);
+						++distinct_node_fetches;
+					}
 				}
 				u32x4 w0, w1, w2, w3, w4;
 				if (node_index < layout.node_count) {
@@ -591,6 +599,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			atomicAdd(&visit_counters[10], (unsigned long long) refill_count);
 			atomicAdd(&visit_counters[16], (unsigned long long) node_pass_count);
 			atomicAdd(&visit_counters[17], (unsigned long long) tri_pass_count);
+			atomicAdd(&visit_counters[24], (unsigned long long) distinct_node_fetches);
 		}
 	}
 }

@@ -1966,8 +1966,20 @@ struct pt_context {
 	std::vector<pt_scene*> scenes;
 	std::vector<int> devices;
 	std::vector<ncclComm_t> comms;
+	// A GPU is listed more than once (PT_CONTEXT_LOOPBACK=1, for tests on a
+	// machine with one GPU): its replicas are summed by a kernel on that GPU,
+	// RCCL has nothing to carry
+	bool loopback;
 	double reduce_ms; // wall time of the last pt_context_reduce()
 };
+
+__global__ void __launch_bounds__(PT_BLOCK) k_add_target(f32x4* sum, const f32x4* term, uint32_t pixel_count) {
+	uint32_t i = blockIdx.x * PT_BLOCK + threadIdx.x;
+	if (i < pixel_count) {
+		f32x4 a = sum[i], b = term[i];
+		sum[i] = mk4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+	}
+}
 
 // After the sum the alpha channel of the first GPU's target holds the number
 // of GPUs whose target was not empty; the reference keeps it at 1 (src/main.c:1015-1017)
@@ -1998,10 +2010,27 @@ static int pt_create_context_impl(pt_context** out_context, const int* device_id
 		printf("pt_create_context() needs between 1 and %d GPU indices.\n", PT_MAX_DEVICES);
 		return 1;
 	}
+	// PT_CONTEXT_LOOPBACK=1 lets a GPU be listed several times: every entry gets
+	// a replica of its own and its own share of the frames, which runs the whole
+	// multi-GPU logic of this file on one GPU (only the reduction cannot go
+	// through RCCL then, which refuses a GPU listed twice)
+	const char* loopback_allowed = getenv("PT_CONTEXT_LOOPBACK");
+	bool loopback = false;
 	for (uint32_t i = 0; i != device_count; ++i) {
 		for (uint32_t j = 0; j != i; ++j) {
 			if (device_ids[i] == device_ids[j]) {
-				printf("pt_create_context() got GPU %d twice.\n", device_ids[i]);
+				if (!(loopback_allowed && loopback_allowed[0] == '1')) {
+					printf("pt_create_context() got GPU %d twice.\n", device_ids[i]);
+					return 1;
+				}
+				loopback = true;
+			}
+		}
+	}
+	if (loopback) {
+		for (uint32_t i = 1; i != device_count; ++i) {
+			if (device_ids[i] != device_ids[0]) {
+				printf("pt_create_context() with PT_CONTEXT_LOOPBACK=1 takes one GPU listed several times, got GPUs %d and %d.\n", device_ids[0], device_ids[i]);
 				return 1;
 			}
 		}
@@ -2010,12 +2039,13 @@ static int pt_create_context_impl(pt_context** out_context, const int* device_id
 	// for two or more (PT_CONTEXT_FORCE_RCCL=1 takes the reduction through RCCL
 	// with one GPU as well, for tests on a one-GPU machine)
 	const char* force_rccl = getenv("PT_CONTEXT_FORCE_RCCL");
-	const bool use_rccl = device_count > 1 || (force_rccl && force_rccl[0] == '1');
+	const bool use_rccl = !loopback && (device_count > 1 || (force_rccl && force_rccl[0] == '1'));
 	if (use_rccl && pt_load_rccl())
 		return 1;
 	pt_context* c = new pt_context();
 	*out_context = c;
 	c->reduce_ms = 0.0;
+	c->loopback = loopback;
 	c->devices.assign(device_ids, device_ids + device_count);
 	c->scenes.assign(device_count, (pt_scene*) NULL);
 	// The replicas are independent (upload, texture decode and BVH build on
@@ -2125,13 +2155,20 @@ static int pt_context_reduce_impl(pt_context* c) {
 		}
 		PT_RCCL_CHECK(pt_rccl.GroupEnd());
 	}
+	else if (c->loopback) {
+		// All replicas live on one GPU and their streams are idle: the first one's stream adds them up
+		PT_CHECK(pt_select_device(root->device));
+		for (uint32_t g = 1; g != n; ++g)
+			hipLaunchKernelGGL(k_add_target, dim3(pt_grid(pixel_count)), dim3(PT_BLOCK), 0, root->stream, root->accum, c->scenes[g]->accum, (uint32_t) pixel_count);
+		PT_CHECK(hipStreamSynchronize(root->stream));
+	}
 	uint32_t total_samples = 0;
 	for (uint32_t g = 0; g != n; ++g) {
 		pt_scene* s = c->scenes[g];
 		total_samples += s->sample_count;
 		PT_CHECK(pt_select_device(s->device));
 		if (g == 0) {
-			if (!c->comms.empty())
+			if (!c->comms.empty() || c->loopback)
 				hipLaunchKernelGGL(k_reset_alpha, dim3(pt_grid(pixel_count)), dim3(PT_BLOCK), 0, s->stream, s->accum, (uint32_t) pixel_count);
 		}
 		else {

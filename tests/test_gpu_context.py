@@ -134,3 +134,81 @@ def test_command_line_driver_on_a_device_list(tmp_path):
         if name == "list.hdr":
             assert "on 1 GPU " in result.stdout and "Summing the render targets over xGMI" in result.stdout
     assert outputs[0] == outputs[1]
+
+
+@pytest.mark.parametrize("replicas", [2, 3, 8])
+def test_context_logic_for_several_gpus_on_one(replicas, monkeypatch):
+    """PT_CONTEXT_LOOPBACK=1: one GPU listed several times gets as many replicas, created by one host thread each,
+    each with its own share of the frames. Everything a context of several GPUs does runs, except that the sum is
+    taken by a kernel instead of RCCL (which refuses a GPU listed twice): slices, the clearing of the other targets
+    after a reduction, the transfer of their sample counts, fewer frames than replicas, rendering on after a reduction."""
+    monkeypatch.setenv("PT_CONTEXT_LOOPBACK", "1")
+    lib = hip_api.lib()
+    scene = synthetic.triangle_soup(seed=33, triangle_count=3000, material_count=3, texture_size=16)
+    lights = synthetic.random_lights(6, 5)
+    width, height = 96, 54
+    constants = to_gpu_constants(oracle.write_constants(synthetic.look_at_spec((0, 9, 0), (np.pi / 2, 0, 0)), width, height, scene, lights))
+    single = gpu_scene(scene, lights)
+    single.set_render_settings(3, 4, scene.emission_material_index)
+    single.create_render_targets(width, height)
+    code, context = create_context(scene, [0] * replicas)
+    assert code == 0 and context.value
+    try:
+        assert lib.pt_context_device_count(context) == replicas
+        light_array = np.ascontiguousarray(lights, np.float32)
+        assert lib.pt_context_set_lights(context, light_array.ctypes.data_as(C.c_void_p), len(light_array)) == 0
+        assert lib.pt_context_set_render_settings(context, 3, 4, scene.emission_material_index) == 0
+        assert lib.pt_context_create_render_targets(context, width, height) == 0
+        root = C.c_void_p(lib.pt_context_scene(context, 0))
+
+        def read(scene_handle):
+            rgba = np.zeros((height, width, 4), np.float32)
+            count = C.c_uint32()
+            assert lib.pt_read_accumulation(scene_handle, rgba.ctypes.data_as(C.c_void_p), C.byref(count)) == 0
+            return rgba, count.value
+
+        def paths_of(scene_handle):
+            stats = hip_api.Statistics()
+            assert lib.pt_get_statistics(scene_handle, C.byref(stats)) == 0
+            return stats.paths
+
+        # 11 frames, then a reduction; then 2 more (fewer than replicas for 3 and 8), another reduction; then a fresh start with 1 frame
+        for first, count, accumulate, expected_total in ((60, 11, 0, 11), (71, 2, 1, 13), (90, 1, 0, 1)):
+            for g in range(replicas):
+                assert lib.pt_reset_statistics(C.c_void_p(lib.pt_context_scene(context, g))) == 0
+            assert lib.pt_context_render_samples(context, C.byref(constants), first, count, accumulate) == 0
+            assert lib.pt_context_synchronize(context) == 0
+            # every replica rendered its slice and nothing else
+            for g in range(replicas):
+                slice_first, slice_count = C.c_uint32(), C.c_uint32()
+                assert lib.pt_context_frame_slice(g, replicas, first, count, C.byref(slice_first), C.byref(slice_count)) == 0
+                assert paths_of(C.c_void_p(lib.pt_context_scene(context, g))) == slice_count.value * width * height
+            assert lib.pt_context_reduce(context) == 0
+            single.render_samples(constants, first, count, accumulate=bool(accumulate))
+            expected, expected_count = single.read_accumulation()
+            got, got_count = read(root)
+            assert got_count == expected_count == expected_total
+            assert (got[..., 3] == 1.0).all()
+            np.testing.assert_allclose(got[..., :3], expected[..., :3], rtol=1e-5, atol=1e-6)
+            # the other replicas start over: nothing is counted twice by the next reduction
+            for g in range(1, replicas):
+                other, other_count = read(C.c_void_p(lib.pt_context_scene(context, g)))
+                assert other_count == 0 and (other == 0.0).all()
+        # reducing again without rendering changes nothing
+        before, _ = read(root)
+        assert lib.pt_context_reduce(context) == 0
+        after, count = read(root)
+        assert count == 1 and (bits(before) == bits(after)).all()
+    finally:
+        lib.pt_destroy_context(context)
+        single.close()
+
+
+def test_loopback_needs_its_switch_and_one_gpu(monkeypatch):
+    scene = synthetic.triangle_soup(seed=32, triangle_count=50, material_count=2, texture_size=8)
+    monkeypatch.delenv("PT_CONTEXT_LOOPBACK", raising=False)
+    code, context = create_context(scene, [0, 0])
+    assert code != 0 and not context.value
+    monkeypatch.setenv("PT_CONTEXT_LOOPBACK", "1")
+    code, context = create_context(scene, [0, 0, 4096])
+    assert code != 0 and not context.value

@@ -77,6 +77,8 @@ def parse_args(argv=None):
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--force-collectives", action="store_true", help="take the one-process-per-GPU code path (process group, all-reduce) even with one rank")
     p.add_argument("--force-context", action="store_true", help="take the one-process-many-GPUs code path (pt_create_context ... pt_context_reduce) even with one GPU")
+    p.add_argument("--devices", default=None,
+                   help="comma-separated GPU indices for the one-process-many-GPUs code path instead of 0..N-1 (their number must be --gpus)")
     p.add_argument("--strong-frames", type=int, default=256, help="frames per step of the strong-scaling leg, shared by all GPUs (0 skips the leg)")
     p.add_argument("--strong-steps", type=int, default=None, help="steps of the strong-scaling leg (default: a quarter of --steps, at least 2)")
     p.add_argument("--workload", choices=sorted(WORKLOADS), default="city",
@@ -335,7 +337,13 @@ def run(args, image_out=None):
         raise SystemExit("bench.py needs a GPU: the HIP library has no CPU fallback")
     if under_launcher and world_size != args.gpus and not args.force_collectives:
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d: the two must agree" % (args.gpus, world_size))
-    if use_context and visible < args.gpus:
+    devices = list(range(args.gpus))
+    if args.devices is not None:
+        devices = [int(d) for d in args.devices.split(",")]
+        use_context = not under_launcher
+        if len(devices) != args.gpus:
+            raise SystemExit("bench.py --gpus %d --devices %s: the list names %d GPUs" % (args.gpus, args.devices, len(devices)))
+    if use_context and (visible < len(set(devices)) or max(devices) >= visible):
         raise SystemExit("bench.py --gpus %d: only %d GPU%s visible to this process; refusing to measure fewer GPUs than asked for" % (args.gpus, visible, " is" if visible == 1 else "s are"))
     torch = None
     if under_launcher:
@@ -355,7 +363,7 @@ def run(args, image_out=None):
     if not args.no_cpu_baseline and rank == 0 and world_size == 1 and not use_context:
         cpu = cpu_baseline(args, host_threads(args.cpu_threads), root, spec.frame_index + 1)
 
-    backend = Context(args, spec, root, range(args.gpus)) if use_context else Ranks(args, spec, root, world_size, rank, local_rank, torch)
+    backend = Context(args, spec, root, devices) if use_context else Ranks(args, spec, root, world_size, rank, local_rank, torch)
     gpu_count = backend.gpu_count
     renderer = backend.renderer
     constants = renderer.constants()

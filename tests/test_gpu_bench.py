@@ -119,3 +119,35 @@ def test_fast_shading_math_stays_within_its_tolerance():
     assert errors[32] < 0.02 and errors[512] < 0.01, errors
     library.set_shading_math(hip_api.SHADING_MATH_EXACT)
     library.close()
+
+
+def test_benchmark_code_path_for_two_gpus_on_one(monkeypatch):
+    """The benchmark's multi-GPU path with two replicas on the one GPU of the box (PT_CONTEXT_LOOPBACK=1): both
+    replicas render their slices, the line adds them up, and the image is the single scene's within the rounding of a
+    different order of additions."""
+    for name in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setenv("PT_CONTEXT_LOOPBACK", "1")
+    width, height, spp, steps, warmup = 128, 72, 3, 2, 1
+    args = bench.parse_args(["--gpus", "2", "--devices", "0,0", "--workload", "cornell", "--width", str(width), "--height", str(height), "--spp-per-step", str(spp),
+                             "--steps", str(steps), "--warmup", str(warmup), "--strong-frames", "5", "--strong-steps", "2", "--no-cpu-baseline"])
+    image = []
+    result = bench.run(args, image_out=image)
+    assert result["n_gpus"] == 2 and result["config"]["spp_total"] == steps * spp * 2
+    per_gpu = result["per_gpu"]
+    assert len(per_gpu) == 2 and all(g["paths"] == width * height * spp * steps for g in per_gpu)
+    rays = sum(g["extension_rays"] + g["shadow_rays"] for g in per_gpu)
+    assert abs(rays / (2 * per_gpu[0]["paths"]) - result["rays_per_path"]) < 1e-12
+    assert result["weak"]["frames_per_step"] == 2 * spp and result["weak"]["frames_per_gpu_and_step"] == spp
+    assert result["strong"]["frames_per_step"] == 5 and result["strong"]["frames_per_gpu_and_step"] == 2.5
+    got, count = image
+    first = result["weak"]["first_frame_index"]
+    spec = host_api.quickload(os.path.join(DATA, "saves", "cornell_box", "default.rt_save"))
+    assert first == spec.frame_index + 1 + (1 + warmup) * spp * 2
+    single = host_api.Renderer(spec, DATA_ROOT, device=0, width=width, height=height)
+    constants = single.constants()
+    assert hip_api.lib().pt_render_samples(single.device_scene, C.byref(constants), first, steps * spp * 2, 1, 0) == 0
+    expected, expected_count = single.read_accumulation()
+    single.close()
+    assert count == expected_count == steps * spp * 2 and (got[..., 3] == 1.0).all()
+    np.testing.assert_allclose(got[..., :3], expected[..., :3], rtol=1e-5, atol=1e-6)

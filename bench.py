@@ -327,10 +327,14 @@ def run(args, image_out=None):
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    under_launcher = ("WORLD_SIZE" in os.environ and "RANK" in os.environ) or args.force_collectives
+    if under_launcher:
+        # A process that uses PyTorch and the HIP library together imports torch first, so that both share one HIP
+        # (and RCCL) runtime; loaded the other way round torch finds no GPU
+        import torch  # noqa: F401
     from path_tracer_amd import hip_api, host_api
     import ctypes as C
     lib = hip_api.lib()
-    under_launcher = ("WORLD_SIZE" in os.environ and "RANK" in os.environ) or args.force_collectives
     use_context = not under_launcher and (args.gpus > 1 or args.force_context)
     visible = int(lib.pt_get_device_count())
     if visible == 0:

@@ -151,3 +151,21 @@ def test_benchmark_code_path_for_two_gpus_on_one(monkeypatch):
     single.close()
     assert count == expected_count == steps * spp * 2 and (got[..., 3] == 1.0).all()
     np.testing.assert_allclose(got[..., :3], expected[..., :3], rtol=1e-5, atol=1e-6)
+
+
+def test_benchmark_under_a_launcher_with_one_rank():
+    """The one-process-per-GPU code path as torch.distributed.run starts it (WORLD_SIZE, RANK, LOCAL_RANK set): process
+    group over RCCL, all-reduce inside the timed region. In a fresh process, because torch has to be loaded before the
+    HIP library there."""
+    import json
+    environment = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collectives", "--workload", "cornell", "--width", "160", "--height", "90",
+                             "--spp-per-step", "4", "--steps", "2", "--warmup", "1", "--strong-frames", "8", "--strong-steps", "1", "--no-cpu-baseline"],
+                            capture_output=True, text=True, timeout=600, env=environment)
+    assert result.returncode == 0, result.stderr[-2000:]
+    line = json.loads(result.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "all-reduce" in line["config"]["parallelism"]
+    assert line["weak"]["frames_per_step"] == 4 and line["strong"]["frames_per_step"] == 8 and line["all_reduce_ms"] > 0
+    # a launcher whose world size differs from --gpus is refused
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cornell", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=environment)
+    assert result.returncode != 0 and "must agree" in result.stderr

@@ -1,12 +1,13 @@
 """pt_trace_rays_no_alloc(): the entry point that allocates nothing, checked through the C ABI against
-pt_trace_rays() bit for bit, twice in a row with the second call on fewer rays (the scratch array keeps what the
-first call left in it)."""
+pt_trace_rays() and against the CPU oracle bit for bit, twice in a row with the second call on fewer rays (the
+scratch array keeps what the first call left in it)."""
 import ctypes as C
 
 import numpy as np
 import pytest
 import torch  # before the HIP library is loaded, so that both share one HIP runtime in this process
 
+import oracle
 from path_tracer_amd import hip_api
 from tests import synthetic
 
@@ -44,16 +45,19 @@ def trace_no_alloc(scene, origins, directions):
 
 
 def test_no_alloc_matches_trace_rays_twice_in_a_row():
-    scene = device_scene(synthetic.triangle_soup(seed=21, triangle_count=20000, material_count=3))
+    soup = synthetic.triangle_soup(seed=21, triangle_count=20000, material_count=3)
+    scene = device_scene(soup)
+    checker = oracle.OracleScene(soup)
     try:
         for seed, count in ((1, 150000), (2, 4321)):
             origins, directions = random_rays(seed, count, 6.0)
             expected = scene.trace_rays(origins, directions)
             got = trace_no_alloc(scene, origins, directions)
             assert (expected[0] >= 0).sum() > count // 10
-            assert np.array_equal(expected[0], got[0])
-            assert np.array_equal(expected[1].view(np.uint32), got[1].view(np.uint32))
-            assert np.array_equal(expected[2], got[2])
+            for reference in (expected, checker.trace_rays(origins, directions)):
+                assert np.array_equal(reference[0], got[0])
+                assert np.array_equal(reference[1].view(np.uint32), got[1].view(np.uint32))
+                assert np.array_equal(reference[2], got[2])
     finally:
         scene.close()
 

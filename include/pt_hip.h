@@ -127,8 +127,8 @@ int pt_set_lights(pt_scene_t* scene, const float* lights, uint32_t count);
 enum { PT_LIGHT_SAMPLING_EXACT = 0, PT_LIGHT_SAMPLING_TREE = 1 };
 int pt_set_light_sampling(pt_scene_t* scene, int light_sampling);
 
-/* The arithmetic of the shading kernel under sampling strategy 3 with
- * PT_LIGHT_SAMPLING_EXACT. EXACT, the default, fuses a multiplication and an
+/* The arithmetic of the shading kernel under sampling strategy 3, with
+ * either way of sampling lights. EXACT, the default, fuses a multiplication and an
  * addition only where the shaders say fma() and rounds every division and
  * square root correctly, as IEEE arithmetic does, which makes images equal a
  * CPU restatement of the shader bit for bit. FAST is what a GPU's shader
@@ -136,7 +136,8 @@ int pt_set_light_sampling(pt_scene_t* scene, int light_sampling);
  * particular rounding: fused multiply-adds, division and square root good to
  * about one unit in the last place, and the bare reciprocal and square root
  * instructions in the two loops over all lights of sample_lights()
- * (src/shaders/pathtrace.frag.glsl:69-83,120-143). Random numbers, primary
+ * (src/shaders/pathtrace.frag.glsl:69-83,120-143; under PT_LIGHT_SAMPLING_TREE
+ * there are no such loops and only the first two freedoms apply). Random numbers, primary
  * rays and their hits stay the same bits; radiance differs like a few more
  * samples would change it (relative RMSE against EXACT at equal seeds below
  * 2 % at 32 samples per pixel and falling with the sample count; image means

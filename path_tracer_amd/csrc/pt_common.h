@@ -276,8 +276,9 @@ struct PtWavefront {
 // by a descent through the light tree instead of a loop over all lights; it
 // has no counterpart in the reference, which stops at 32 lights.
 // NEE_FAST is NEE with the hardware's approximate reciprocal and square root (one unit in the last place) in the
-// loops over all lights, where NEE rounds every quotient and root correctly; it exists on the GPU only
-enum { PT_STRATEGY_SPHERICAL = 0, PT_STRATEGY_PSA = 1, PT_STRATEGY_BRDF = 2, PT_STRATEGY_NEE = 3, PT_STRATEGY_NEE_TREE = 4, PT_STRATEGY_NEE_FAST = 5 };
+// loops over all lights, where NEE rounds every quotient and root correctly; it exists on the GPU only.
+// NEE_TREE_FAST is NEE_TREE in the translation unit that is built with a shader compiler's freedoms
+enum { PT_STRATEGY_SPHERICAL = 0, PT_STRATEGY_PSA = 1, PT_STRATEGY_BRDF = 2, PT_STRATEGY_NEE = 3, PT_STRATEGY_NEE_TREE = 4, PT_STRATEGY_NEE_FAST = 5, PT_STRATEGY_NEE_TREE_FAST = 6 };
 
 // How one batch of paths maps to pixels and frames: path p belongs to frame
 // slot p / paths_per_frame and to the 8x8 pixel tile (p % paths_per_frame) / 64

@@ -1417,10 +1417,10 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 			case PT_STRATEGY_PSA: hipLaunchKernelGGL(k_shade<PT_STRATEGY_PSA>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a); break;
 			case PT_STRATEGY_BRDF: hipLaunchKernelGGL(k_shade<PT_STRATEGY_BRDF>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a); break;
 			default:
-				if (tree)
+				if (s->shading_math == PT_SHADING_MATH_FAST)
+					pt_launch_shade_fast(pt_grid_chunked(path_count, PT_SHADE_BLOCK), lds, s->stream, a, tree);
+				else if (tree)
 					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE_TREE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a);
-				else if (s->shading_math == PT_SHADING_MATH_FAST)
-					pt_launch_shade_fast(pt_grid_chunked(path_count, PT_SHADE_BLOCK), lds, s->stream, a);
 				else
 					hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE>, dim3(pt_grid_chunked(path_count, PT_SHADE_BLOCK)), dim3(PT_SHADE_BLOCK), lds, s->stream, a);
 				break;

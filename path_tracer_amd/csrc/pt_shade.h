@@ -1194,7 +1194,8 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 	r.next_cone = 0.0f;
 	// In the NEE estimator emission is weighted by nee_throughput, in the
 	// others by throughput (pathtrace.frag.glsl:231,265,293,323)
-	bool next_event_estimation = strategy == PT_STRATEGY_NEE || strategy == PT_STRATEGY_NEE_TREE || strategy == PT_STRATEGY_NEE_FAST;
+	bool light_tree = strategy == PT_STRATEGY_NEE_TREE || strategy == PT_STRATEGY_NEE_TREE_FAST;
+	bool next_event_estimation = strategy == PT_STRATEGY_NEE || strategy == PT_STRATEGY_NEE_FAST || light_tree;
 	v3 emission_weight = next_event_estimation ? nee_throughput : throughput;
 	if (hit_prim == 0xffffffffu) {
 		emitted = emission_weight * mk3(c.sky_radiance[0], c.sky_radiance[1], c.sky_radiance[2]);
@@ -1245,7 +1246,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		PtLightTreeSample tree_sample;
 		tree_sample.leaf = 0;
 		tree_sample.probability = 0.0f;
-		v3 light_dir = (strategy == PT_STRATEGY_NEE_TREE)
+		v3 light_dir = light_tree
 			? pt_sample_lights_tree(scene, &sampled_light_density, &tree_sample, s.pos, s.normal, pt_random(sx, sy))
 			: pt_sample_lights(scene, light_cache, &total_light_importance, s.pos, s.normal, pt_random(sx, sy), strategy == PT_STRATEGY_NEE_FAST);
 		float lambert_in_0 = dot(s.normal, light_dir);
@@ -1253,7 +1254,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		float lambert_in_1 = dot(s.normal, r.next_dir);
 		float light_density_0 = 0.0f, light_density_1 = 0.0f;
 		if (lambert_in_0 > 0.0f || lambert_in_1 > 0.0f) {
-			if (strategy == PT_STRATEGY_NEE_TREE) {
+			if (light_tree) {
 				pt_lights_density_tree_2(scene, tree_sample, s.pos, s.normal, light_dir, r.next_dir, &light_density_0, &light_density_1);
 				// Like max(1, count) at pathtrace.frag.glsl:172-173: the sampled
 				// light counts even if rounding lets its own ray miss it

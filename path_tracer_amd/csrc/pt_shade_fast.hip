@@ -7,6 +7,9 @@
 // inline functions that both translation units share are the same on the host.
 #include "pt_shade_kernel.h"
 
-void pt_launch_shade_fast(uint32_t grid, size_t dynamic_lds_bytes, hipStream_t stream, const PtShadeArgs& args) {
-	hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE_FAST>, dim3(grid), dim3(PT_SHADE_BLOCK), dynamic_lds_bytes, stream, args);
+void pt_launch_shade_fast(uint32_t grid, size_t dynamic_lds_bytes, hipStream_t stream, const PtShadeArgs& args, bool light_tree) {
+	if (light_tree)
+		hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE_TREE_FAST>, dim3(grid), dim3(PT_SHADE_BLOCK), dynamic_lds_bytes, stream, args);
+	else
+		hipLaunchKernelGGL(k_shade<PT_STRATEGY_NEE_FAST>, dim3(grid), dim3(PT_SHADE_BLOCK), dynamic_lds_bytes, stream, args);
 }

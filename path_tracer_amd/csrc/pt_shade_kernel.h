@@ -232,6 +232,6 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(PtShad
 }
 
 
-// k_shade<PT_STRATEGY_NEE_FAST>, compiled in pt_shade_fast.hip with fused
+// k_shade<PT_STRATEGY_NEE_FAST> or, with light_tree, k_shade<PT_STRATEGY_NEE_TREE_FAST>, compiled in pt_shade_fast.hip with fused
 // multiply-adds and approximate division and square root in device code
-void pt_launch_shade_fast(uint32_t grid, size_t dynamic_lds_bytes, hipStream_t stream, const PtShadeArgs& args);
+void pt_launch_shade_fast(uint32_t grid, size_t dynamic_lds_bytes, hipStream_t stream, const PtShadeArgs& args, bool light_tree);

@@ -82,9 +82,11 @@ def test_accumulating_into_an_empty_target_takes_the_discard_pipeline():
     renderer.close()
 
 
-def test_fast_shading_math_stays_within_its_tolerance():
+@pytest.mark.parametrize("light_sampling", [hip_api.LIGHT_SAMPLING_EXACT, hip_api.LIGHT_SAMPLING_TREE])
+def test_fast_shading_math_stays_within_its_tolerance(light_sampling):
     """pt_set_shading_math(PT_SHADING_MATH_FAST): the shading kernel with fused multiply-adds, approximate division
-    and square root, and bare reciprocals in the loops over all lights. Primary hits are the same bits (they do not
+    and square root, and bare reciprocals in the loops over all lights (or, with the light tree, in its descent and
+    its probabilities). Primary hits are the same bits (they do not
     depend on it); radiance at equal seeds differs from the exact mode in the last bits nearly everywhere, and by more
     where such a difference moves a sample across the boundary between two lights or two triangles: relative RMSE
     below 2 % at 32 samples per pixel, below 1 % at 512, image means within 0.1 %."""
@@ -97,6 +99,7 @@ def test_fast_shading_math_stays_within_its_tolerance():
     library = gpu_scene(scene, lights)
     library.create_render_targets(width, height)
     library.set_render_settings(3, 4, scene.emission_material_index)
+    library.set_light_sampling(light_sampling)
     images = {}
     for spp in (32, 512):
         for mode in (hip_api.SHADING_MATH_EXACT, hip_api.SHADING_MATH_FAST):

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(PT_BLOCK) k_raygen(PtBatch batch, const PtCons
 // something emissive (pathtrace.frag.glsl:323-325); the hit record then names a triangle that answers that like the
 // closest one (see pt_trace_wave())
 template <bool COUNT_VISITS, bool EMISSIVE_ONLY>
-__global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_trace_extension(PtTraceArgs a) {
+__global__ void __launch_bounds__(PT_TRACE_BLOCK, PT_WAVES_PER_BLOCK * PT_TRACE_BLOCKS_PER_CU / 4) k_trace_extension(PtTraceArgs a) {
 	__shared__ PtTraceLds lds;
 	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
 	PtRayQueue queue;
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_
 // trace_ray_emission() of pathtrace.frag.glsl:203-219 and the MIS sum at :338
 // EMISSIVE_ONLY: with the skipping of pt_trace_wave() (the nodes and triangles must carry the marks for it)
 template <bool COUNT_VISITS, bool EMISSIVE_ONLY>
-__global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_trace_shadow(PtTraceArgs a) {
+__global__ void __launch_bounds__(PT_TRACE_BLOCK, PT_WAVES_PER_BLOCK * PT_TRACE_BLOCKS_PER_CU / 4) k_trace_shadow(PtTraceArgs a) {
 	__shared__ PtTraceLds lds;
 	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
 	PtRayQueue queue;
@@ -428,7 +428,7 @@ struct PtUserRayArgs {
 	uint8_t* front;
 };
 
-__global__ void __launch_bounds__(PT_TRACE_BLOCK, 4 * PT_TRACE_BLOCKS_PER_CU) k_trace_user_rays(PtUserRayArgs a) {
+__global__ void __launch_bounds__(PT_TRACE_BLOCK, PT_WAVES_PER_BLOCK * PT_TRACE_BLOCKS_PER_CU / 4) k_trace_user_rays(PtUserRayArgs a) {
 	__shared__ PtTraceLds lds;
 	pt_fill_cache(lds, a.cache_layout, a.scene.nodes, a.scene.tris);
 	PtRayQueue queue;

@@ -30,8 +30,10 @@
 #include "pt_common.h"
 #include "pt_trace.h"
 
-#define PT_TRACE_BLOCK 1024   // threads per workgroup of the traversal kernels
+#ifndef PT_WAVES_PER_BLOCK
 #define PT_WAVES_PER_BLOCK 16
+#endif
+#define PT_TRACE_BLOCK (64 * PT_WAVES_PER_BLOCK) // threads per workgroup of the traversal kernels
 #define PT_VISIT_COUNTERS 32 // 64-bit words of visit counters and diagnostics
 #ifndef PT_TRACE_BLOCKS_PER_CU
 #define PT_TRACE_BLOCKS_PER_CU 2 // workgroups that share a CU and its LDS: 32 waves, the most a CU holds
@@ -55,6 +57,9 @@
 #endif
 #ifndef PT_TRIS_PER_PASS
 #define PT_TRIS_PER_PASS 1   // triangle tests per lane and pass
+#endif
+#ifndef PT_PIPELINE
+#define PT_PIPELINE 0        // 1: the node of the next pass is requested before the triangle test of this one
 #endif
 
 // Bits of the error word that the traversal sets when it had to give up on rays
@@ -277,6 +282,159 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	(void) node_pass_count; (void) tri_pass_count;
 	unsigned long long active_lane_passes = 0;
 
+	// The node step in three parts. select_node(): which node a lane without
+	// pending triangles looks at next (the next child of the current group or,
+	// when that is used up, of the group on top of the stack); false if there is
+	// none. load_node() requests its words, test_node() tests its eight boxes
+	// and leaves the children that were hit in ngroup and tgroup.
+	u32x4 w0, w1, w2, w3, w4;
+	uint32_t node_index;
+	// PT_PIPELINE: the words of a node are on their way (or there) and its boxes not yet tested
+	bool fetched = false;
+	auto select_node = [&]() -> bool {
+		if (EMISSIVE_ONLY && (emissive_state & 1u)) {
+			// Of the children still to be entered, only the marked ones (the
+			// second byte holds the marks in the order of the first)
+			uint32_t marked = ngroup.y & ((ngroup.y << 16) | 0x00ffffffu);
+			emissive_state |= (marked != ngroup.y) ? 2u : 0u;
+			ngroup.y = marked;
+		}
+		if (!(ngroup.y & 0xff000000u) && sp != 0) {
+			--sp;
+			pt_vec2 entry;
+			if (sp < PT_WAVE_STACK)
+				entry = *(const pt_lds_vec2*) &lds.stack[sp][lane];
+			else
+				entry = *(const pt_global_vec2*) &stack_overflow[(uint64_t) (sp - PT_WAVE_STACK) * stack_overflow_stride];
+			ngroup.x = entry.x;
+			ngroup.y = entry.y;
+			if (EMISSIVE_ONLY && (emissive_state & 1u)) {
+				uint32_t marked = ngroup.y & ((ngroup.y << 16) | 0x00ffffffu);
+				emissive_state |= (marked != ngroup.y) ? 2u : 0u;
+				ngroup.y = marked;
+			}
+		}
+		if (!(ngroup.y & 0xff000000u))
+			return false;
+		uint32_t bit = 31u - (uint32_t) __builtin_clz(ngroup.y);
+		ngroup.y &= ~(1u << bit);
+		if (ngroup.y & 0xff000000u) {
+			pt_vec2 entry;
+			entry.x = ngroup.x;
+			entry.y = ngroup.y;
+			if (sp < PT_WAVE_STACK)
+				*(pt_lds_vec2*) &lds.stack[sp][lane] = entry;
+			else if (sp < stack_capacity)
+				*(pt_global_vec2*) &stack_overflow[(uint64_t) (sp - PT_WAVE_STACK) * stack_overflow_stride] = entry;
+			if (sp < stack_capacity)
+				++sp;
+			else
+				atomicOr(error_word, PT_ERROR_STACK_OVERFLOW);
+		}
+		uint32_t child_slot = (bit - 24u) ^ octinv;
+		uint32_t rel = (uint32_t) __builtin_popcount(ngroup.y & 0xffu & ((1u << child_slot) - 1u));
+		node_index = ngroup.x + rel;
+		if (COUNT_VISITS) {
+			++node_visits;
+			lds_node_visits += (node_index < layout.node_count) ? 1u : 0u;
+			// How many different nodes the lanes of this pass fetch: what a walk
+			// that shared the fetch and the stack among the lanes would visit
+			unsigned long long todo = __ballot(true);
+			while (todo) {
+				uint32_t first = (uint32_t) __builtin_amdgcn_readlane((int) node_index, (int) __builtin_ctzll(todo));
+				todo &= ~__ballot(node_index == first);
+				++distinct_node_fetches;
+			}
+		}
+		return true;
+	};
+	auto load_node = [&]() {
+		if (node_index < layout.node_count) {
+			const u32x4* words = &cache[5 * node_index];
+			w0 = pt_load_lds(words); w1 = pt_load_lds(words + 1); w2 = pt_load_lds(words + 2); w3 = pt_load_lds(words + 3); w4 = pt_load_lds(words + 4);
+		}
+		else {
+			const u32x4* words = (const u32x4*) &nodes[node_index];
+			w0 = pt_load_global(words); w1 = pt_load_global(words + 1); w2 = pt_load_global(words + 2); w3 = pt_load_global(words + 3); w4 = pt_load_global(words + 4);
+		}
+	};
+	auto test_node = [&]() {
+		float sx = pt_as_float((w0.w & 0xffu) << 23), sy = pt_as_float(((w0.w >> 8) & 0xffu) << 23), sz = pt_as_float(((w0.w >> 16) & 0xffu) << 23);
+		uint32_t imask = w0.w >> 24;
+		float ax = idx * sx, ay = idy * sy, az = idz * sz;
+		float dx = pt_as_float(w0.x) - origin.x, dy = pt_as_float(w0.y) - origin.y, dz = pt_as_float(w0.z) - origin.z;
+		float bx = dx * idx, by = dy * idy, bz = dz * idz;
+		// Near planes a little nearer, far planes a little farther (pt_box_test_slack())
+		float slack = 2.0f * pt_box_test_slack(dx, dy, dz, sx, sy, sz);
+		float ex = slack * fabsf(idx), ey = slack * fabsf(idy), ez = slack * fabsf(idz);
+		float bxn = bx - ex, byn = by - ey, bzn = bz - ez, bxf = bx + ex, byf = by + ey, bzf = bz + ez;
+		// Near and far planes per axis, chosen once per node by the ray's signs
+		uint32_t nqx[2] = { pt_select_bits(neg_x, w3.z, w2.x), pt_select_bits(neg_x, w3.w, w2.y) }, fqx[2] = { pt_select_bits(neg_x, w2.x, w3.z), pt_select_bits(neg_x, w2.y, w3.w) };
+		uint32_t nqy[2] = { pt_select_bits(neg_y, w4.x, w2.z), pt_select_bits(neg_y, w4.y, w2.w) }, fqy[2] = { pt_select_bits(neg_y, w2.z, w4.x), pt_select_bits(neg_y, w2.w, w4.y) };
+		uint32_t nqz[2] = { pt_select_bits(neg_z, w4.z, w3.x), pt_select_bits(neg_z, w4.w, w3.y) }, fqz[2] = { pt_select_bits(neg_z, w3.x, w4.z), pt_select_bits(neg_z, w3.y, w4.w) };
+		uint32_t leafmask = w1.z & 0xffu;
+		// Eight box tests back to back without branches: bit i of hit8 says
+		// whether child slot i was hit (empty slots are masked out below).
+		// tn <= tf is read off the sign of tf - tn, shifted into the mask
+		// from the last child to the first: a subtraction and a funnel
+		// shift per child instead of a comparison, a conditional move and
+		// an or. tn and tf are no NaNs (the maxima and minima drop them),
+		// equal values give +0, and should two infinities of one sign make
+		// the difference a NaN, its sign bit is clear: the child counts as
+		// hit, which costs a visit and no more.
+		uint32_t missed8 = 0;
+#pragma unroll
+		for (int i = 7; i >= 0; --i) {
+			float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bxn), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bxf);
+			float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, byn), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, byf);
+			float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bzn), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bzf);
+			float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+			float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
+			missed8 = __builtin_amdgcn_alignbit(missed8, pt_as_uint(tf - tn), 31);
+		}
+		uint32_t hit8 = ~missed8 & 0xffu;
+		if (COUNT_VISITS) {
+			// Node steps that found nothing, and among them those that would have found
+			// something without the closest hit so far (the node was put on the stack
+			// before that hit was known)
+			bool empty = (hit8 & (imask | leafmask)) == 0u;
+			empty_node_visits += empty ? 1u : 0u;
+			uint32_t missed8_unbounded = 0;
+#pragma unroll
+			for (int i = 7; i >= 0; --i) {
+				float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bxn), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bxf);
+				float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, byn), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, byf);
+				float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bzn), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bzf);
+				float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
+				float tf = fminf(fminf(fx, fy), fz);
+				missed8_unbounded = __builtin_amdgcn_alignbit(missed8_unbounded, pt_as_uint(tf - tn), 31);
+			}
+			culled_by_hit_visits += (empty && (~missed8_unbounded & (imask | leafmask) & 0xffu) != 0u) ? 1u : 0u;
+		}
+		if (EMISSIVE_ONLY && (emissive_state & 1u)) {
+			uint32_t marked = hit8 & (w1.z >> 8);
+			emissive_state |= (marked != hit8) ? 2u : 0u;
+			hit8 = marked;
+		}
+		// Inner children: from slot order to visiting order (slot ^ octinv),
+		// three conditional swaps of neighbouring bits, pairs and nibbles
+		// (with EMISSIVE_ONLY the marks of those children ride along in the
+		// second byte and end up in the same order)
+		uint32_t order = (hit8 & imask) | (EMISSIVE_ONLY ? (w1.z & (imask << 8)) : 0u);
+		uint32_t swap = ((order >> 1) ^ order) & (0x5555u & ~neg_x);
+		order ^= swap | (swap << 1);
+		swap = ((order >> 2) ^ order) & (0x3333u & ~neg_y);
+		order ^= swap | (swap << 2);
+		swap = ((order >> 4) ^ order) & (0x0f0fu & ~neg_z);
+		order ^= swap | (swap << 4);
+		ngroup.x = w1.x;
+		ngroup.y = (order << 24) | (order & 0xff00u) | imask;
+		// Triangles pending in the low byte (by slot), the leaf mask above
+		// it: a triangle's index is tri_base plus the leaves below its slot
+		tgroup.x = w1.y;
+		tgroup.y = (hit8 & leafmask) | (leafmask << 8);
+	};
+
 	// Every pass retires, fetches, walks or tests something, so the loop ends
 	// when the queue is used up; the bound only guards the GPU against a logic
 	// error ever hanging it. Running into it, or into the end of the stack,
@@ -364,6 +522,13 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 						octinv = 7u - ((neg_x & 1u) | (neg_y & 2u) | (neg_z & 4u));
 						ngroup.x = 0;
 						ngroup.y = 0x80000000u;
+#if PT_PIPELINE
+						// The root (in the LDS prefix) at once, so that its boxes are tested in this pass
+						if (select_node()) {
+							load_node();
+							fetched = true;
+						}
+#endif
 					}
 				}
 				reserve_next += (want < available) ? want : available;
@@ -381,146 +546,77 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			break;
 		}
 
+#if PT_PIPELINE
+		// ---- boxes of the node that was requested in the previous pass ----
+		if (COUNT_VISITS)
+			node_pass_count += __ballot(fetched) != 0;
+		if (fetched) {
+			test_node();
+			fetched = false;
+		}
+		// ---- request one triangle per lane that has triangles pending ----
+		bool triangle_requested = active && (tgroup.y & 0xffu) != 0;
+		if (COUNT_VISITS)
+			tri_pass_count += __ballot(triangle_requested) != 0;
+		u32x4 t0, t1, t2;
+		if (triangle_requested) {
+			uint32_t bit = (uint32_t) __builtin_ctz(tgroup.y);
+			tgroup.y &= tgroup.y - 1u;
+			uint32_t tri_index = tgroup.x + (uint32_t) __builtin_popcount((tgroup.y >> 8) & ((1u << bit) - 1u));
+			if (COUNT_VISITS) {
+				++tri_visits;
+				lds_tri_visits += (tri_index < layout.tri_count) ? 1u : 0u;
+			}
+			if (tri_index < layout.tri_count) {
+				const u32x4* words = &cache[layout.tri_offset + 3 * tri_index];
+				t0 = pt_load_lds(words); t1 = pt_load_lds(words + 1); t2 = pt_load_lds(words + 2);
+			}
+			else {
+				const u32x4* words = (const u32x4*) &tris[tri_index];
+				t0 = pt_load_global(words); t1 = pt_load_global(words + 1); t2 = pt_load_global(words + 2);
+			}
+		}
+		// ---- request the node of the next pass, behind the triangle: the triangle test
+		// below waits for the triangle only and runs while the node is on its way.
+		// Which node comes next does not depend on that test (the closest hit so far
+		// enters the box test, which comes after it as before; with EMISSIVE_ONLY a
+		// child may be entered that the test would have ruled out, which costs a visit) ----
+		if (active && (tgroup.y & 0xffu) == 0) {
+			if (select_node()) {
+				load_node();
+				fetched = true;
+			}
+		}
+		// ---- test the triangle ----
+		if (triangle_requested) {
+			pt_intersect_triangle_lane(hit, shear, origin,
+				mk3(pt_as_float(t0.x), pt_as_float(t0.y), pt_as_float(t0.z)),
+				mk3(pt_as_float(t0.w), pt_as_float(t1.x), pt_as_float(t1.y)),
+				mk3(pt_as_float(t1.z), pt_as_float(t1.w), pt_as_float(t2.x)), t2.y, tmin);
+			if (EMISSIVE_ONLY && hit.prim == t2.y) {
+				// This triangle is the closest hit now
+				if (t2.z != 0u)
+					emissive_state &= ~1u;
+				else if (emissive_state & 4u) {
+					// Second walk: an occluder in front of the emissive hit answers the question
+					sp = 0;
+					ngroup.y = 0;
+					tgroup.y = 0;
+					fetched = false;
+				}
+				else
+					emissive_state |= 1u;
+			}
+		}
+
+#else
 		if (COUNT_VISITS)
 			node_pass_count += __ballot(active && (tgroup.y & 0xffu) == 0) != 0;
 		// ---- one node per lane that has no triangles pending ----
 		if (active && (tgroup.y & 0xffu) == 0) {
-			if (EMISSIVE_ONLY && (emissive_state & 1u)) {
-				// Of the children still to be entered, only the marked ones (the
-				// second byte holds the marks in the order of the first)
-				uint32_t marked = ngroup.y & ((ngroup.y << 16) | 0x00ffffffu);
-				emissive_state |= (marked != ngroup.y) ? 2u : 0u;
-				ngroup.y = marked;
-			}
-			if (!(ngroup.y & 0xff000000u) && sp != 0) {
-				--sp;
-				pt_vec2 entry;
-				if (sp < PT_WAVE_STACK)
-					entry = *(const pt_lds_vec2*) &lds.stack[sp][lane];
-				else
-					entry = *(const pt_global_vec2*) &stack_overflow[(uint64_t) (sp - PT_WAVE_STACK) * stack_overflow_stride];
-				ngroup.x = entry.x;
-				ngroup.y = entry.y;
-				if (EMISSIVE_ONLY && (emissive_state & 1u)) {
-					uint32_t marked = ngroup.y & ((ngroup.y << 16) | 0x00ffffffu);
-					emissive_state |= (marked != ngroup.y) ? 2u : 0u;
-					ngroup.y = marked;
-				}
-			}
-			if (ngroup.y & 0xff000000u) {
-				uint32_t bit = 31u - (uint32_t) __builtin_clz(ngroup.y);
-				ngroup.y &= ~(1u << bit);
-				if (ngroup.y & 0xff000000u) {
-					pt_vec2 entry;
-					entry.x = ngroup.x;
-					entry.y = ngroup.y;
-					if (sp < PT_WAVE_STACK)
-						*(pt_lds_vec2*) &lds.stack[sp][lane] = entry;
-					else if (sp < stack_capacity)
-						*(pt_global_vec2*) &stack_overflow[(uint64_t) (sp - PT_WAVE_STACK) * stack_overflow_stride] = entry;
-					if (sp < stack_capacity)
-						++sp;
-					else
-						atomicOr(error_word, PT_ERROR_STACK_OVERFLOW);
-				}
-				uint32_t child_slot = (bit - 24u) ^ octinv;
-				uint32_t rel = (uint32_t) __builtin_popcount(ngroup.y & 0xffu & ((1u << child_slot) - 1u));
-				uint32_t node_index = ngroup.x + rel;
-				if (COUNT_VISITS) {
-					++node_visits;
-					lds_node_visits += (node_index < layout.node_count) ? 1u : 0u;
-					// How many different nodes the lanes of this pass fetch: what a walk
-					// that shared the fetch and the stack among the lanes would visit
-					unsigned long long todo = __ballot(true);
-					while (todo) {
-						uint32_t first = (uint32_t) __builtin_amdgcn_readlane((int) node_index, (int) __builtin_ctzll(todo));
-						todo &= ~__ballot(node_index == first);
-						++distinct_node_fetches;
-					}
-				}
-				u32x4 w0, w1, w2, w3, w4;
-				if (node_index < layout.node_count) {
-					const u32x4* words = &cache[5 * node_index];
-					w0 = pt_load_lds(words); w1 = pt_load_lds(words + 1); w2 = pt_load_lds(words + 2); w3 = pt_load_lds(words + 3); w4 = pt_load_lds(words + 4);
-				}
-				else {
-					const u32x4* words = (const u32x4*) &nodes[node_index];
-					w0 = pt_load_global(words); w1 = pt_load_global(words + 1); w2 = pt_load_global(words + 2); w3 = pt_load_global(words + 3); w4 = pt_load_global(words + 4);
-				}
-				float sx = pt_as_float((w0.w & 0xffu) << 23), sy = pt_as_float(((w0.w >> 8) & 0xffu) << 23), sz = pt_as_float(((w0.w >> 16) & 0xffu) << 23);
-				uint32_t imask = w0.w >> 24;
-				float ax = idx * sx, ay = idy * sy, az = idz * sz;
-				float dx = pt_as_float(w0.x) - origin.x, dy = pt_as_float(w0.y) - origin.y, dz = pt_as_float(w0.z) - origin.z;
-				float bx = dx * idx, by = dy * idy, bz = dz * idz;
-				// Near planes a little nearer, far planes a little farther (pt_box_test_slack())
-				float slack = 2.0f * pt_box_test_slack(dx, dy, dz, sx, sy, sz);
-				float ex = slack * fabsf(idx), ey = slack * fabsf(idy), ez = slack * fabsf(idz);
-				float bxn = bx - ex, byn = by - ey, bzn = bz - ez, bxf = bx + ex, byf = by + ey, bzf = bz + ez;
-				// Near and far planes per axis, chosen once per node by the ray's signs
-				uint32_t nqx[2] = { pt_select_bits(neg_x, w3.z, w2.x), pt_select_bits(neg_x, w3.w, w2.y) }, fqx[2] = { pt_select_bits(neg_x, w2.x, w3.z), pt_select_bits(neg_x, w2.y, w3.w) };
-				uint32_t nqy[2] = { pt_select_bits(neg_y, w4.x, w2.z), pt_select_bits(neg_y, w4.y, w2.w) }, fqy[2] = { pt_select_bits(neg_y, w2.z, w4.x), pt_select_bits(neg_y, w2.w, w4.y) };
-				uint32_t nqz[2] = { pt_select_bits(neg_z, w4.z, w3.x), pt_select_bits(neg_z, w4.w, w3.y) }, fqz[2] = { pt_select_bits(neg_z, w3.x, w4.z), pt_select_bits(neg_z, w3.y, w4.w) };
-				uint32_t leafmask = w1.z & 0xffu;
-				// Eight box tests back to back without branches: bit i of hit8 says
-				// whether child slot i was hit (empty slots are masked out below).
-				// tn <= tf is read off the sign of tf - tn, shifted into the mask
-				// from the last child to the first: a subtraction and a funnel
-				// shift per child instead of a comparison, a conditional move and
-				// an or. tn and tf are no NaNs (the maxima and minima drop them),
-				// equal values give +0, and should two infinities of one sign make
-				// the difference a NaN, its sign bit is clear: the child counts as
-				// hit, which costs a visit and no more.
-				uint32_t missed8 = 0;
-#pragma unroll
-				for (int i = 7; i >= 0; --i) {
-					float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bxn), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bxf);
-					float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, byn), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, byf);
-					float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bzn), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bzf);
-					float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
-					float tf = fminf(fminf(fx, fy), fminf(fz, hit.t));
-					missed8 = __builtin_amdgcn_alignbit(missed8, pt_as_uint(tf - tn), 31);
-				}
-				uint32_t hit8 = ~missed8 & 0xffu;
-				if (COUNT_VISITS) {
-					// Node steps that found nothing, and among them those that would have found
-					// something without the closest hit so far (the node was put on the stack
-					// before that hit was known)
-					bool empty = (hit8 & (imask | leafmask)) == 0u;
-					empty_node_visits += empty ? 1u : 0u;
-					uint32_t missed8_unbounded = 0;
-#pragma unroll
-					for (int i = 7; i >= 0; --i) {
-						float nx = fmaf(pt_byte_to_float(nqx[i >> 2], i & 3), ax, bxn), fx = fmaf(pt_byte_to_float(fqx[i >> 2], i & 3), ax, bxf);
-						float ny = fmaf(pt_byte_to_float(nqy[i >> 2], i & 3), ay, byn), fy = fmaf(pt_byte_to_float(fqy[i >> 2], i & 3), ay, byf);
-						float nz = fmaf(pt_byte_to_float(nqz[i >> 2], i & 3), az, bzn), fz = fmaf(pt_byte_to_float(fqz[i >> 2], i & 3), az, bzf);
-						float tn = fmaxf(fmaxf(nx, ny), fmaxf(nz, tmin));
-						float tf = fminf(fminf(fx, fy), fz);
-						missed8_unbounded = __builtin_amdgcn_alignbit(missed8_unbounded, pt_as_uint(tf - tn), 31);
-					}
-					culled_by_hit_visits += (empty && (~missed8_unbounded & (imask | leafmask) & 0xffu) != 0u) ? 1u : 0u;
-				}
-				if (EMISSIVE_ONLY && (emissive_state & 1u)) {
-					uint32_t marked = hit8 & (w1.z >> 8);
-					emissive_state |= (marked != hit8) ? 2u : 0u;
-					hit8 = marked;
-				}
-				// Inner children: from slot order to visiting order (slot ^ octinv),
-				// three conditional swaps of neighbouring bits, pairs and nibbles
-				// (with EMISSIVE_ONLY the marks of those children ride along in the
-				// second byte and end up in the same order)
-				uint32_t order = (hit8 & imask) | (EMISSIVE_ONLY ? (w1.z & (imask << 8)) : 0u);
-				uint32_t swap = ((order >> 1) ^ order) & (0x5555u & ~neg_x);
-				order ^= swap | (swap << 1);
-				swap = ((order >> 2) ^ order) & (0x3333u & ~neg_y);
-				order ^= swap | (swap << 2);
-				swap = ((order >> 4) ^ order) & (0x0f0fu & ~neg_z);
-				order ^= swap | (swap << 4);
-				ngroup.x = w1.x;
-				ngroup.y = (order << 24) | (order & 0xff00u) | imask;
-				// Triangles pending in the low byte (by slot), the leaf mask above
-				// it: a triangle's index is tri_base plus the leaves below its slot
-				tgroup.x = w1.y;
-				tgroup.y = (hit8 & leafmask) | (leafmask << 8);
+			if (select_node()) {
+				load_node();
+				test_node();
 			}
 		}
 
@@ -564,8 +660,9 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			}
 		}
 
+#endif
 		// ---- retire complete rays ----
-		if (active && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0) {
+		if (active && !fetched && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0) {
 			if (EMISSIVE_ONLY && emissive_state == 2u) {
 				// Emissive, but not everything in front of it has been looked at
 				emissive_state = 4u;

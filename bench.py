@@ -145,8 +145,10 @@ def host_threads(requested=None):
 
 
 def generated_lights(count, factor, summand):
-    """count lights uniform in the bounding box of the quantised positions (21 bits per axis)."""
-    rng = np.random.default_rng(4)
+    """count lights uniform in the bounding box of the quantised positions (21 bits per axis), radii in [0.1, 0.5]:
+    stream 4 of the generators' random numbers (procedural.Pcg2d)."""
+    from path_tracer_amd.tools import procedural
+    rng = procedural.Pcg2d(4)
     low = np.asarray(summand, np.float64)
     high = low + np.asarray(factor, np.float64) * float((1 << 21) - 1)
     lights = np.zeros((count, 4), np.float32)

@@ -20,6 +20,57 @@ from . import vks, vkt
 EMISSION_MATERIAL = "_emission"
 
 
+class Pcg2d:
+    """The random numbers of the generators: the shader's own generator (get_random_numbers(),
+    src/shaders/pathtrace.frag.glsl:23-34), so that a scene can be generated again without numpy's generators.
+
+    Number pair i of a stream (i counts from 0 over all draws of the object) is the state uvec2(i mod 2^32,
+    seed + (i >> 32)) advanced once by that function; its two words x, y give the uniform numbers (x + 0.5) / 2^32 and
+    (y + 0.5) / 2^32 in float64, in that order (never 0 or 1). A draw of n numbers uses ceil(n / 2) pairs and drops the
+    last number when n is odd. Normal numbers are Box-Muller over one pair each: sqrt(-2 ln u_x) cos(2 pi u_y), then
+    the same with sin, in float64. Arrays are filled in C order."""
+
+    def __init__(self, seed):
+        self.seed, self.counter = int(seed), 0
+
+    def _pairs(self, count):
+        index = self.counter + np.arange(count, dtype=np.uint64)
+        self.counter += count
+        x = (index & np.uint64(0xffffffff)).astype(np.uint32)
+        y = ((index >> np.uint64(32)) + np.uint64(self.seed & 0xffffffff)).astype(np.uint32)
+        multiplier, increment, shift = np.uint32(1664525), np.uint32(1013904223), np.uint32(16)
+        with np.errstate(over="ignore"):
+            x, y = x * multiplier + increment, y * multiplier + increment
+            x = x + y * multiplier
+            y = y + x * multiplier
+            x, y = x ^ (x >> shift), y ^ (y >> shift)
+            x = x + y * multiplier
+            y = y + x * multiplier
+            x, y = x ^ (x >> shift), y ^ (y >> shift)
+        return x, y
+
+    def _unit(self, count):
+        x, y = self._pairs((count + 1) // 2)
+        numbers = np.stack([x, y], axis=1).reshape(-1)[:count]
+        return (numbers.astype(np.float64) + 0.5) / 4294967296.0
+
+    def uniform(self, low=0.0, high=1.0, size=None):
+        low, high = np.asarray(low, np.float64), np.asarray(high, np.float64)
+        shape = np.broadcast_shapes(low.shape, high.shape) if size is None else (tuple(size) if np.ndim(size) else (int(size),))
+        numbers = low + (high - low) * self._unit(int(np.prod(shape, dtype=np.int64))).reshape(shape)
+        return float(numbers) if numbers.ndim == 0 else numbers
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        shape = () if size is None else (tuple(size) if np.ndim(size) else (int(size),))
+        count = int(np.prod(shape, dtype=np.int64))
+        x, y = self._pairs((count + 1) // 2)
+        radius = np.sqrt(-2.0 * np.log((x.astype(np.float64) + 0.5) / 4294967296.0))
+        angle = 2.0 * np.pi * (y.astype(np.float64) + 0.5) / 4294967296.0
+        numbers = np.stack([radius * np.cos(angle), radius * np.sin(angle)], axis=1).reshape(-1)[:count].reshape(shape)
+        numbers = loc + scale * numbers
+        return float(numbers) if numbers.ndim == 0 else numbers
+
+
 class _Mesh:
     def __init__(self):
         self.positions, self.uvs, self.materials = [], [], []
@@ -177,7 +228,7 @@ def generate_city(root, triangles=2800000, lights_file=None, save_file=None, mat
     a cobbled ground, trees, and a lamp (pole + emissive sphere) at every light of lights_file (the reference's
     Bistro_outside.lights when given). Streets are kept free around the lamps and in front of the camera of the
     reference's bistro/outside quicksave. Returns the triangle count."""
-    rng = np.random.default_rng(seed)
+    rng = Pcg2d(seed)
     if lights_file is not None:
         raw = np.fromfile(lights_file, np.uint8)
         lights = raw[4:].view(np.float32).reshape(-1, 4).astype(np.float64)
@@ -202,7 +253,7 @@ def generate_city(root, triangles=2800000, lights_file=None, save_file=None, mat
 
     def build(cell, leaf_count):
         mesh = _Mesh()
-        local = np.random.default_rng(seed + 1)
+        local = Pcg2d(seed + 1)
         for i, (lot, height) in enumerate(zip(lots, heights)):
             _building(mesh, local, *lot, height, cell, i % (material_count - 5), roof)
         n = max(1, int((hi[0] - lo[0]) / (2.0 * cell)))
@@ -219,7 +270,20 @@ def generate_city(root, triangles=2800000, lights_file=None, save_file=None, mat
     fixed = len(lights) * (1280 + 12 + 12)
     leaf_count = int(0.2 * triangles / max(1, len(tree_spots)))
     cell = (2.0 * (facade_area + ground_area) / max(1.0, triangles - fixed - leaf_count * len(tree_spots))) ** 0.5
+
+    def count(cell):
+        """The triangles that build(cell, leaf_count) makes."""
+        total = len(lights) * (1280 + 12) + len(tree_spots) * (12 + leaf_count)
+        for (x0, y0, x1, y1), height in zip(lots, heights):
+            nu_w, nu_d, nv = max(1, int(round((x1 - x0) / cell))), max(1, int(round((y1 - y0) / cell))), max(1, int(round(height / cell)))
+            total += 4 * (nu_w + nu_d) * nv + 2 * max(1, nu_w // 2) * max(1, nu_d // 2)
+        return total + 2 * max(1, int((hi[0] - lo[0]) / (2.0 * cell))) ** 2
+
+    # The estimate above is good to a few tenths of a per cent; the scene has at least the triangles asked for
+    while count(cell) < triangles:
+        cell *= 0.9995
     mesh = build(cell, leaf_count)
+    assert mesh.count() == count(cell)
 
     def save_writer(path):
         if save_file is not None:
@@ -232,7 +296,7 @@ def generate_city(root, triangles=2800000, lights_file=None, save_file=None, mat
 def generate_interior(root, triangles=1000000, light_count=32, material_count=24, texture_size=256, seed=2):
     """A hall in the place of data/Arcade.*: displaced walls, floor and ceiling, rows of cabinets and light_count
     ceiling lamps, each an analytic spherical light with emissive geometry. Returns the triangle count."""
-    rng = np.random.default_rng(seed)
+    rng = Pcg2d(seed)
     sx, sy, sz = 24.0, 16.0, 5.0
     columns = int(np.ceil(light_count ** 0.5 * (sx / sy) ** 0.5))
     rows = int(np.ceil(light_count / columns))
@@ -245,25 +309,32 @@ def generate_interior(root, triangles=1000000, light_count=32, material_count=24
     cabinet_area = len(cabinets) * (2.0 * (1.2 + 0.8) * 1.9 + 1.2 * 0.8)
     cell = ((area + cabinet_area) * 2.0 / max(1.0, triangles - light_count * 1280)) ** 0.5
 
-    def panel(origin, du, dv, material, amplitude=0.02):
-        nu, nv = max(1, int(np.linalg.norm(du) / cell)), max(1, int(np.linalg.norm(dv) / cell))
+    panels = [((0, 0, 0), (sx, 0, 0), (0, sy, 0), 0, 0.02),                 # floor, normal +z
+              ((0, 0, sz), (0, sy, 0), (sx, 0, 0), 1, 0.02),                # ceiling, normal -z
+              ((0, 0, 0), (0, 0, sz), (sx, 0, 0), 2, 0.02),                 # wall y = 0, normal +y
+              ((0, sy, 0), (sx, 0, 0), (0, 0, sz), 3, 0.02),                # wall y = sy, normal -y
+              ((0, 0, 0), (0, sy, 0), (0, 0, sz), 4, 0.02),                 # wall x = 0, normal +x
+              ((sx, 0, 0), (0, 0, sz), (0, sy, 0), 5, 0.02)]                # wall x = sx, normal -x
+    for i, (x, y) in enumerate(cabinets):
+        material = 6 + i % (material_count - 7)
+        panels += [((x, y, 0), (1.2, 0, 0), (0, 0, 1.9), material, 0.05), ((x + 1.2, y, 0), (0, 0.8, 0), (0, 0, 1.9), material, 0.05),
+                   ((x + 1.2, y + 0.8, 0), (-1.2, 0, 0), (0, 0, 1.9), material, 0.05), ((x, y + 0.8, 0), (0, -0.8, 0), (0, 0, 1.9), material, 0.05),
+                   ((x, y, 1.9), (1.2, 0, 0), (0, 0.8, 0), material, 0.01)]
+
+    def divisions(du, dv, cell):
+        return max(1, int(np.linalg.norm(du) / cell)), max(1, int(np.linalg.norm(dv) / cell))
+
+    def count(cell):
+        return light_count * 1280 + sum(2 * int(np.prod(divisions(du, dv, cell))) for _, du, dv, _, _ in panels)
+
+    # At least the triangles asked for (the estimate of the cell size is good to about a per cent)
+    while count(cell) < triangles:
+        cell *= 0.999
+    for origin, du, dv, material, amplitude in panels:
+        nu, nv = divisions(du, dv, cell)
         u, v = np.arange(nu + 1) / nu * np.linalg.norm(du), np.arange(nv + 1) / nv * np.linalg.norm(dv)
         relief = amplitude * (np.sin(u * 5.0)[None, :] * np.sin(v * 5.0)[:, None]) + rng.uniform(-0.004, 0.004, (nv + 1, nu + 1))
         _grid(mesh, origin, du, dv, nu, nv, relief, material)
-
-    panel((0, 0, 0), (sx, 0, 0), (0, sy, 0), 0)                  # floor, normal +z
-    panel((0, 0, sz), (0, sy, 0), (sx, 0, 0), 1)                 # ceiling, normal -z
-    panel((0, 0, 0), (0, 0, sz), (sx, 0, 0), 2)                  # wall y = 0, normal +y
-    panel((0, sy, 0), (sx, 0, 0), (0, 0, sz), 3)                 # wall y = sy, normal -y
-    panel((0, 0, 0), (0, sy, 0), (0, 0, sz), 4)                  # wall x = 0, normal +x
-    panel((sx, 0, 0), (0, 0, sz), (0, sy, 0), 5)                 # wall x = sx, normal -x
-    for i, (x, y) in enumerate(cabinets):
-        material = 6 + i % (material_count - 7)
-        panel((x, y, 0), (1.2, 0, 0), (0, 0, 1.9), material, 0.05)
-        panel((x + 1.2, y, 0), (0, 0.8, 0), (0, 0, 1.9), material, 0.05)
-        panel((x + 1.2, y + 0.8, 0), (-1.2, 0, 0), (0, 0, 1.9), material, 0.05)
-        panel((x, y + 0.8, 0), (0, -0.8, 0), (0, 0, 1.9), material, 0.05)
-        panel((x, y, 1.9), (1.2, 0, 0), (0, 0.8, 0), material, 0.01)
     _light_spheres(mesh, lights, emission)
 
     def save_writer(path):

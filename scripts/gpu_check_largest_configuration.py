@@ -57,7 +57,7 @@ phase[0] = "parsing the scene with numpy"
 data = os.path.join(root, "data")
 scene = formats.load_scene(os.path.join(data, "Bistro_outside.vks"), os.path.join(data, "Bistro_textures"))
 check(scene.triangle_count >= TRIANGLES, "%d triangles, %d materials" % (scene.triangle_count, len(scene.material_names)))
-rng = np.random.default_rng(4)
+rng = procedural.Pcg2d(4)
 low = scene.dequantization_summand.astype(np.float64)
 high = low + scene.dequantization_factor.astype(np.float64) * float((1 << 21) - 1)
 lights = np.zeros((10000, 4), np.float32)

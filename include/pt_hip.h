@@ -122,8 +122,10 @@ int pt_set_lights(pt_scene_t* scene, const float* lights, uint32_t count);
  * (src/main.c:691-694): one descent through a binary tree over the lights per
  * vertex and a lookup of the lights that a sampled direction meets in a grid
  * over them, for scenes with thousands of lights; the estimate stays
- * unbiased, its noise differs. The default is EXACT; the other strategies
- * ignore it. */
+ * unbiased, its noise differs. A surface point inside the sphere of a light
+ * takes no sample of that light under TREE (the reference's formulas at
+ * :69-106 leave their domain there and EXACT follows them, negative radiance
+ * included). The default is EXACT; the other strategies ignore it. */
 enum { PT_LIGHT_SAMPLING_EXACT = 0, PT_LIGHT_SAMPLING_TREE = 1 };
 int pt_set_light_sampling(pt_scene_t* scene, int light_sampling);
 

@@ -1091,6 +1091,15 @@ static vec3 sample_lights_tree(const context_t* ctx, float* out_density, vec3 sh
 		}
 	}
 	const float* l = &ctx->tree_lights[4 * (size_t) (node - ctx->light_leaf_count)];
+	/* A shading point inside the light's sphere gets no sample of that light:
+	   the density below counts a light only for rays that start outside of it
+	   (the condition of :167), and the formulas of :69-106 suppose a point
+	   outside (inside, the "cone" is wider than a hemisphere and the sampled
+	   vector, whose z goes below -1, is no direction any more). Emission seen
+	   from inside is found by the BRDF sample, with a light density of zero. */
+	vec3 center_dir = sub3(v3(l[0], l[1], l[2]), shading_pos);
+	if (!(dot3(center_dir, center_dir) - l[3] * l[3] >= 0.0f))
+		return v3(0.0f, 0.0f, 0.0f);
 	float importance = get_spherical_light_importance(v3(l[0], l[1], l[2]), l[3], shading_pos, normal);
 	if (!(importance > 0.0f))
 		return v3(0.0f, 0.0f, 0.0f);

@@ -814,6 +814,15 @@ PT_FN v3 pt_sample_lights_tree(const PtSceneView& scene, float* out_density, PtL
 	out_sample->leaf = node;
 	out_sample->probability = probability;
 	f32x4 light = scene.tree_lights[node - scene.light_leaf_count];
+	// No sample of a light from inside its sphere: pt_ray_meets_light() counts a
+	// light only for rays that start outside of it, and the formulas of
+	// pathtrace.frag.glsl:69-106 suppose a point outside (inside, z_range exceeds
+	// one, z goes below -1 and the sampled vector is no direction any more, which
+	// the BRDF answers with negative values). Emission seen from inside is found
+	// by the BRDF sample, with a light density of zero.
+	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
+	if (!(dot(center_dir, center_dir) - light.w * light.w >= 0.0f))
+		return mk3(0.0f, 0.0f, 0.0f);
 	float importance = pt_spherical_light_importance(light, shading_pos, normal);
 	if (!(importance > 0.0f))
 		return mk3(0.0f, 0.0f, 0.0f);

@@ -165,6 +165,34 @@ def test_furnace_in_a_box():
         assert 0.4 < means[-1] < 1.0, (strategy, means)
 
 
+def test_a_surface_inside_the_sphere_of_a_light():
+    """A floor under a sky of radiance one and a light of radius one whose centre lies 0.3 below the floor (no
+    emitter: the light only steers the sampling). Seen from inside the sphere the formulas of
+    pathtrace.frag.glsl:69-106 leave their domain: z_range exceeds one, z = 1 - z_range * u goes below -1, the vector
+    returned points away from the centre, out of the floor, with a length of two and more, and the Fresnel factors
+    of the diffuse lobe (brdfs.glsl:29-31) are negative for such a "cosine". The loops over all lights follow the
+    reference there, negative radiance included (pinned here as its behaviour, not endorsed). The light tree, which
+    has no counterpart in the reference, takes no sample of a light from inside its sphere, in line with its density,
+    which counts a light only for rays that start outside of it: what is left is the BRDF sample with a light density
+    of zero, the same bits as a render without any light; kernel body and oracle agree."""
+    material = dict(base_color=(0.8, 0.8, 0.8), roughness=0.9, metalicity=0.0)
+    scene, no_lights, constants, towards_camera = furnace_setup(material)
+    light = np.array([[0.0, 0.0, -0.3, 1.0]], np.float32)
+    lit_constants = constants  # the lights of a render are an argument of their own
+    s = oracle.OracleScene(scene)
+    spp = 64
+    plain, plain_rays = s.render(constants, no_lights, strategy=3, path_length=2, first_frame_index=3, frame_count=spp, threads=4)
+    assert plain[..., :3].min() > 0.0
+    loops, _ = s.render(lit_constants, light, strategy=3, path_length=2, first_frame_index=3, frame_count=spp, threads=4)
+    assert np.isfinite(loops).all() and loops[..., :3].min() < 0.0
+    tree, tree_rays = s.render(lit_constants, light, strategy=3, path_length=2, first_frame_index=3, frame_count=spp, threads=4, light_sampling=1)
+    assert tree_rays == plain_rays and (tree.view(np.uint32) == plain.view(np.uint32)).all()
+    emulated = emu.EmuScene(scene)
+    emulated.set_lights(light)
+    got, got_rays = emulated.render(lit_constants, strategy=4, path_length=2, first_frame_index=3, frame_count=spp)
+    assert got_rays == tree_rays and (got.view(np.uint32) == tree.view(np.uint32)).all()
+
+
 def test_estimators_agree_per_channel(cornell, cornell_lights, cornell_spec, oracle_cornell):
     """The four sampling strategies estimate the same integral on the reference's own scene, light included
     (pathtrace.frag.glsl:224,258,286,315): image means per channel within their standard errors."""

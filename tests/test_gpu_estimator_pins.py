@@ -73,3 +73,28 @@ def test_floor_under_a_unit_sky_reflects_its_directional_albedo(material):
     reference, _ = oracle.OracleScene(scene).render(constants, no_lights, strategy=3, path_length=2, first_frame_index=7, frame_count=3, threads=16)
     assert same(got, reference)
     library.close()
+
+
+def test_a_surface_inside_the_sphere_of_a_light():
+    """tests/test_estimator_pins.py::test_a_surface_inside_the_sphere_of_a_light through the library: the loops over
+    all lights follow the reference into negative radiance, the light tree takes no sample of a light from inside its
+    sphere and renders the bits of a scene without lights; both equal the oracle."""
+    from path_tracer_amd import hip_api
+    material = dict(base_color=(0.8, 0.8, 0.8), roughness=0.9, metalicity=0.0)
+    scene, no_lights, constants, towards_camera = furnace_setup(material)
+    light = np.array([[0.0, 0.0, -0.3, 1.0]], np.float32)
+    checker = oracle.OracleScene(scene)
+    spp = 64
+    images = {}
+    for name, lights, light_sampling in (("plain", no_lights, 0), ("loops", light, 0), ("tree", light, 1)):
+        library = gpu_scene(scene, lights)
+        library.create_render_targets(16, 16)
+        library.set_render_settings(3, 2, scene.emission_material_index)
+        library.set_light_sampling(hip_api.LIGHT_SAMPLING_TREE if light_sampling else hip_api.LIGHT_SAMPLING_EXACT)
+        library.render_samples(to_gpu_constants(constants), 3, spp, 1, accumulate=False)
+        images[name], _ = library.read_accumulation()
+        library.close()
+        reference, _ = checker.render(constants, lights, strategy=3, path_length=2, first_frame_index=3, frame_count=spp, threads=16, light_sampling=light_sampling)
+        assert same(images[name], reference), name
+    assert images["loops"][..., :3].min() < 0.0 and images["plain"][..., :3].min() > 0.0
+    assert same(images["tree"], images["plain"])

@@ -348,3 +348,4 @@ def test_traversal_against_a_loop_over_all_triangles(distance):
     assert (expected[0] >= 0).mean() > 0.6
     for got in (e_scene.trace_rays(origins, directions), o_scene.trace_rays(origins, directions)):
         assert (got[0] == expected[0]).all() and (bits(got[1]) == bits(expected[1])).all() and (got[2] == expected[2]).all()
+

@@ -49,7 +49,8 @@ def workload_root(args, rank, barrier=None):
         return DATA_ROOT
     from path_tracer_amd.tools import procedural
     triangles = args.triangles or WORKLOADS[args.workload][4]
-    root = os.path.join(args.scene_cache, "%s_%d%s" % (args.workload, triangles, "_t%d" % args.texture_size if args.texture_size else ""))
+    # The generator's revision is part of the name, so that a scene left by an earlier revision is not taken for this one's
+    root = os.path.join(args.scene_cache, "%s_%d%s_g%d" % (args.workload, triangles, "_t%d" % args.texture_size if args.texture_size else "", procedural.REVISION))
     if rank == 0:
         options = {"triangles": triangles}
         if args.texture_size:

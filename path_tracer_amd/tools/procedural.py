@@ -18,6 +18,9 @@ import numpy as np
 from . import vks, vkt
 
 EMISSION_MATERIAL = "_emission"
+# Counts the changes of what the generators make of the same arguments (2: random numbers from Pcg2d, triangle counts
+# not below what was asked for)
+REVISION = 2
 
 
 class Pcg2d:

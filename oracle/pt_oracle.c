@@ -1055,17 +1055,31 @@ static void build_light_tree(const float* lights, uint32_t count, float** out_no
 	*out_leaf_count = leaf_count;
 }
 
-/* Selection weight of a node seen from a shading point: power over squared
-   distance (at least the squared half diagonal), zero below the horizon */
-static float light_node_weight(const context_t* ctx, uint32_t node, vec3 shading_pos, vec3 normal) {
+/* Selection weight of a node seen from a shading point as a fraction: power
+   over squared distance (at least the squared half diagonal); the power is
+   zero for an empty node and below the horizon */
+static void light_node_weight(const context_t* ctx, uint32_t node, vec3 shading_pos, vec3 normal, float* out_power, float* out_distance_2) {
 	const float* n = &ctx->light_nodes[8 * (size_t) node];
+	*out_power = 0.0f;
+	*out_distance_2 = 1.0f;
 	if (!(n[3] > 0.0f))
-		return 0.0f;
+		return;
 	vec3 center_dir = sub3(v3(n[0], n[1], n[2]), shading_pos);
 	float reach = (fabsf(normal.x) * n[4] + fabsf(normal.y) * n[5]) + fabsf(normal.z) * n[6];
 	if (dot3(normal, center_dir) + reach < 0.0f)
-		return 0.0f;
-	return n[3] / fmaxf(dot3(center_dir, center_dir), n[7]);
+		return;
+	*out_power = n[3];
+	*out_distance_2 = fmaxf(dot3(center_dir, center_dir), n[7]);
+}
+
+/* The weights of the children 2i and 2i + 1 over a common denominator (only
+   their proportion matters): p0 / d0 : p1 / d1 = p0 * d1 : p1 * d0 */
+static void light_child_weights(const context_t* ctx, uint32_t left_child, vec3 shading_pos, vec3 normal, float* w0, float* w1) {
+	float p0, d0, p1, d1;
+	light_node_weight(ctx, left_child, shading_pos, normal, &p0, &d0);
+	light_node_weight(ctx, left_child + 1, shading_pos, normal, &p1, &d1);
+	*w0 = p0 * d1;
+	*w1 = p1 * d0;
 }
 
 static vec3 sample_lights_tree(const context_t* ctx, float* out_density, vec3 shading_pos, vec3 normal, vec2 randoms) {
@@ -1073,8 +1087,8 @@ static vec3 sample_lights_tree(const context_t* ctx, float* out_density, vec3 sh
 	uint32_t node = 1;
 	float probability = 1.0f;
 	while (node < ctx->light_leaf_count) {
-		float w0 = light_node_weight(ctx, 2 * node, shading_pos, normal);
-		float w1 = light_node_weight(ctx, 2 * node + 1, shading_pos, normal);
+		float w0, w1;
+		light_child_weights(ctx, 2 * node, shading_pos, normal, &w0, &w1);
 		float total = w0 + w1;
 		if (!(total > 0.0f))
 			return v3(0.0f, 0.0f, 0.0f);
@@ -1115,8 +1129,8 @@ static float light_selection_probability(const context_t* ctx, uint32_t leaf_nod
 	float probability = 1.0f;
 	for (uint32_t level = 1; level <= depth; ++level) {
 		uint32_t node = leaf_node >> (depth - level);
-		float w0 = light_node_weight(ctx, node & ~1u, shading_pos, normal);
-		float w1 = light_node_weight(ctx, node | 1u, shading_pos, normal);
+		float w0, w1;
+		light_child_weights(ctx, node & ~1u, shading_pos, normal, &w0, &w1);
 		float w = (node & 1u) ? w1 : w0;
 		if (!(w > 0.0f))
 			return 0.0f;

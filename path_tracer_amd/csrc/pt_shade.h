@@ -762,18 +762,41 @@ PT_FN void pt_lights_density_2(const PtSceneView& scene, float total_importance,
 
 // ---- Light tree (structure and estimator: pt_light_tree.h) ----
 
-// Weight of a node for the descent from a shading point: zero for an empty
-// node and for one whose box lies below the horizon of the shading point
-PT_FN float pt_light_node_weight(const f32x4* nodes, uint32_t node, v3 shading_pos, v3 normal) {
+// Weight of a node for the descent from a shading point, as a fraction: its
+// power over the squared distance to the centre of its box (at least the
+// squared half diagonal). The power is zero for an empty node and for one whose
+// box lies below the horizon of the shading point.
+struct PtLightNodeWeight {
+	float power, distance_2;
+};
+
+PT_FN PtLightNodeWeight pt_light_node_weight(const f32x4* nodes, uint32_t node, v3 shading_pos, v3 normal) {
+	PtLightNodeWeight weight;
+	weight.power = 0.0f;
+	weight.distance_2 = 1.0f;
 	f32x4 center_power = nodes[2 * node], half_radius = nodes[2 * node + 1];
 	if (!(center_power.w > 0.0f))
-		return 0.0f;
+		return weight;
 	v3 center_dir = mk3(center_power.x, center_power.y, center_power.z) - shading_pos;
 	// The largest dot(normal, x - shading_pos) over the points x of the box
 	float reach = (fabsf(normal.x) * half_radius.x + fabsf(normal.y) * half_radius.y) + fabsf(normal.z) * half_radius.z;
 	if (dot(normal, center_dir) + reach < 0.0f)
-		return 0.0f;
-	return center_power.w / fmaxf(dot(center_dir, center_dir), half_radius.w);
+		return weight;
+	weight.power = center_power.w;
+	weight.distance_2 = fmaxf(dot(center_dir, center_dir), half_radius.w);
+	return weight;
+}
+
+// The weights of the two children of a node over a common denominator:
+// power_0 / distance_0 : power_1 / distance_1 = power_0 * distance_1 :
+// power_1 * distance_0. The descent and the probability of a leaf want their
+// proportion only, and a product costs a twelfth of a correctly rounded
+// quotient.
+PT_FN void pt_light_child_weights(const f32x4* nodes, uint32_t left_child, v3 shading_pos, v3 normal, float* out_weight_0, float* out_weight_1) {
+	PtLightNodeWeight w0 = pt_light_node_weight(nodes, left_child, shading_pos, normal);
+	PtLightNodeWeight w1 = pt_light_node_weight(nodes, left_child + 1u, shading_pos, normal);
+	*out_weight_0 = w0.power * w1.distance_2;
+	*out_weight_1 = w1.power * w0.distance_2;
 }
 
 // The leaf that a descent of pt_sample_lights_tree() arrived at (0: none) and
@@ -798,8 +821,8 @@ PT_FN v3 pt_sample_lights_tree(const PtSceneView& scene, float* out_density, PtL
 	uint32_t node = 1;
 	float probability = 1.0f;
 	while (node < scene.light_leaf_count) {
-		float weight_0 = pt_light_node_weight(scene.light_nodes, 2 * node, shading_pos, normal);
-		float weight_1 = pt_light_node_weight(scene.light_nodes, 2 * node + 1, shading_pos, normal);
+		float weight_0, weight_1;
+		pt_light_child_weights(scene.light_nodes, 2 * node, shading_pos, normal, &weight_0, &weight_1);
 		float total = weight_0 + weight_1;
 		if (!(total > 0.0f))
 			return mk3(0.0f, 0.0f, 0.0f);
@@ -836,8 +859,8 @@ PT_FN float pt_light_tree_probability(const PtSceneView& scene, uint32_t leaf_no
 	float probability = 1.0f;
 	for (uint32_t shift = 31u - (uint32_t) __builtin_clz(leaf_node); shift-- != 0;) {
 		uint32_t node = leaf_node >> shift;
-		float weight_0 = pt_light_node_weight(scene.light_nodes, node & ~1u, shading_pos, normal);
-		float weight_1 = pt_light_node_weight(scene.light_nodes, node | 1u, shading_pos, normal);
+		float weight_0, weight_1;
+		pt_light_child_weights(scene.light_nodes, node & ~1u, shading_pos, normal, &weight_0, &weight_1);
 		float weight = (node & 1u) ? weight_1 : weight_0;
 		if (!(weight > 0.0f))
 			return 0.0f;

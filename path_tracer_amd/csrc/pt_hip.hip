@@ -1610,6 +1610,8 @@ static int pt_get_statistics_impl(pt_scene_t* s, pt_statistics_t* out) {
 				100.0 * (double) visits[20 + 2 * k] / (double) (visits[2 * k] ? visits[2 * k] : 1), 100.0 * (double) visits[21 + 2 * k] / (double) (visits[1 + 2 * k] ? visits[1 + 2 * k] : 1));
 			printf("trace diagnostics (%s): %.1f%% of the node steps found no child to enter and no triangle to test, %.1f%% would have without the closest hit found since the node was put on the stack\n", k ? "shadow" : "extension",
 				100.0 * (double) visits[12 + 2 * k] / (double) (visits[2 * k] ? visits[2 * k] : 1), 100.0 * (double) visits[13 + 2 * k] / (double) (visits[2 * k] ? visits[2 * k] : 1));
+			printf("trace diagnostics (%s): %.1f%% of the node steps belong to rays that only look for something emissive in front of their hit, %.1f%% to second walks\n", k ? "shadow" : "extension",
+				100.0 * (double) visits[28 + 2 * k] / (double) (visits[2 * k] ? visits[2 * k] : 1), 100.0 * (double) visits[29 + 2 * k] / (double) (visits[2 * k] ? visits[2 * k] : 1));
 			printf("trace diagnostics (%s): the lanes of a pass with a node step fetch %.1f different nodes on average (%.1f lanes take part)\n", k ? "shadow" : "extension",
 				(double) visits[24 + 2 * k] / (double) (visits[16 + 2 * k] ? visits[16 + 2 * k] : 1), (double) visits[2 * k] / (double) (visits[16 + 2 * k] ? visits[16 + 2 * k] : 1));
 			printf("trace diagnostics (%s): wave passes %llu, lanes holding a ray %.1f%%, refills %llu, passes with a node step %llu (%.1f%% of lanes in them), with a triangle test %llu (%.1f%%)\n",

@@ -278,6 +278,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	// something was skipped on that account; bit 2: this is the second walk
 	uint32_t emissive_state = 0;
 	uint32_t node_visits = 0, tri_visits = 0, lds_node_visits = 0, lds_tri_visits = 0, empty_node_visits = 0, culled_by_hit_visits = 0, distinct_node_fetches = 0;
+	uint32_t skipping_node_visits = 0, second_walk_node_visits = 0;
 	uint32_t pass_count = 0, refill_count = 0, node_pass_count = 0, tri_pass_count = 0;
 	(void) node_pass_count; (void) tri_pass_count;
 	unsigned long long active_lane_passes = 0;
@@ -337,6 +338,9 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		if (COUNT_VISITS) {
 			++node_visits;
 			lds_node_visits += (node_index < layout.node_count) ? 1u : 0u;
+			// Node steps of rays that only look for something emissive in front of their hit, and of second walks
+			skipping_node_visits += (EMISSIVE_ONLY && (emissive_state & 1u)) ? 1u : 0u;
+			second_walk_node_visits += (EMISSIVE_ONLY && (emissive_state & 4u)) ? 1u : 0u;
 			// How many different nodes the lanes of this pass fetch: what a walk
 			// that shared the fetch and the stack among the lanes would visit
 			unsigned long long todo = __ballot(true);
@@ -689,6 +693,8 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 		atomicAdd(&visit_counters[21], (unsigned long long) lds_tri_visits);
 		atomicAdd(&visit_counters[12], (unsigned long long) empty_node_visits);
 		atomicAdd(&visit_counters[13], (unsigned long long) culled_by_hit_visits);
+		atomicAdd(&visit_counters[28], (unsigned long long) skipping_node_visits);
+		atomicAdd(&visit_counters[29], (unsigned long long) second_walk_node_visits);
 		if (lane == 0) {
 			// Diagnostics: passes, lanes active in them, refills (summed over waves)
 			atomicAdd(&visit_counters[6], (unsigned long long) pass_count);

@@ -33,6 +33,7 @@ HBM_PEAK_GBS = 8000.0
 # A SIMD issues one VALU wave instruction every two cycles (16 lanes wide, 64-lane waves take four cycles, two
 # waves alternate): 1024 SIMDs at 2.4 GHz issue at most this many wave instructions per second
 VALU_PEAK_WAVE_INSTRUCTIONS_PER_S = 1024 * 2.4e9 / 2.0
+MEASURED_CYCLES_PER_WAVE_INSTRUCTION = 2.4
 PMC_FILE = os.path.join("profiles", "pmc_current.json")
 
 # workload -> (scene name, texture directory, quicksave below data/saves, label, default triangle budget)
@@ -465,6 +466,10 @@ def run(args, image_out=None):
             "traffic": counters["hbm_bytes_per_launch"] if counters else None,
             "traffic_source": (counter_source and "%s via %s (separate rocprofv3 --pmc passes of this command, not this run)" % (counter_source, PMC_FILE)),
             "hbm_frac": hbm_frac, "valu_issue_frac": valu_issue_frac,
+            # The same against what streams of independent instructions were measured to issue on this part: one wave64
+            # instruction per 2.4 instead of 2 cycles of the nominal clock (scripts/valu_rates.hip,
+            # profiles/r3/valu_instruction_costs.txt)
+            "valu_issue_frac_of_measured_rate": valu_issue_frac * MEASURED_CYCLES_PER_WAVE_INSTRUCTION / 2.0 if valu_issue_frac is not None else None,
             "valu_lane_utilisation": counters.get("valu_lane_utilisation") if counters else None,
             "valu_instructions_per_launch": counters.get("valu_instructions_per_launch") if counters else None,
             "l2_hit_rate": counters.get("l2_hit_rate") if counters else None,

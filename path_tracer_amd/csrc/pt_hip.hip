@@ -293,9 +293,9 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, PT_WAVES_PER_BLOCK * PT_TRACE_
 	queue.direction = a.wf.sh_d;
 	queue.count = &a.wf.shadow_count[a.bounce];
 	queue.fetch = a.fetch;
-	pt_trace_wave<COUNT_VISITS, EMISSIVE_ONLY>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
+	pt_trace_wave<COUNT_VISITS, EMISSIVE_ONLY, true>(lds.wave[threadIdx.x >> 6], lds.cache, a.cache_layout, a.scene.nodes, a.scene.tris, a.scene.triangle_count, queue,
 		a.stack_overflow + (blockIdx.x * PT_TRACE_BLOCK + threadIdx.x), a.stack_overflow_stride, a.stack_capacity, a.visit_counters ? a.visit_counters + 2 : NULL, a.error_word,
-		[&](uint32_t slot, float path_bits, float factor, const PtHit& hit) {
+		[&](uint32_t slot, float path_bits, float, const PtHit& hit) {
 			const PtConstants& c = *a.constants;
 			v3 emission;
 			if (hit.prim == PT_INVALID)
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, PT_WAVES_PER_BLOCK * PT_TRACE_
 			else
 				emission = mk3(0.0f, 0.0f, 0.0f);
 			f32x4 w = pt_load_streaming(&a.wf.sh_w[slot]);
-			v3 term = (mk3(w.x, w.y, w.z) * emission) * factor;
+			v3 term = (mk3(w.x, w.y, w.z) * emission) * w.w;
 			// Adding a zero leaves the radiance as it is (it is never -0), so the
 			// read-modify-write happens only for terms that are not zero; a NaN
 			// from an infinite weight compares unequal and is added as well

@@ -699,6 +699,19 @@ PT_FN v3 pt_sample_spherical_light(f32x4 light, float importance, v3 shading_pos
 	return pt_to_world(frame, mk3(r * ca, r * sa, z));
 }
 
+// How far from a shading point the sphere of a light begins, roughly (zero
+// inside): shadow rays carry it so that the traversal can tell a hit in front
+// of the light they aim at from one behind it. It steers work, not results, so
+// the hardware's square root will do.
+PT_FN float pt_light_near_distance(f32x4 light, v3 shading_pos) {
+	v3 center_dir = mk3(light.x, light.y, light.z) - shading_pos;
+#if defined(__HIP_DEVICE_COMPILE__)
+	return fmaxf(0.0f, __builtin_amdgcn_sqrtf(dot(center_dir, center_dir)) - light.w);
+#else
+	return fmaxf(0.0f, sqrtf(dot(center_dir, center_dir)) - light.w);
+#endif
+}
+
 // Where pt_sample_lights() keeps the importances of its first loop for its
 // second one: entry i of a thread is at values[i * stride]. The reference
 // evaluates get_spherical_light_importance() anew in both loops; the values
@@ -709,7 +722,7 @@ struct PtLightCache {
 };
 
 // ---- pathtrace.frag.glsl:120-143 ----
-PT_FN v3 pt_sample_lights(const PtSceneView& scene, const PtLightCache& cache, float* out_total_importance, v3 shading_pos, v3 normal, v2 randoms, bool fast = false) {
+PT_FN v3 pt_sample_lights(const PtSceneView& scene, const PtLightCache& cache, float* out_total_importance, v3 shading_pos, v3 normal, v2 randoms, bool fast = false, float* out_near_distance = NULL) {
 	float total = 0.0f;
 	PT_LIGHT_LOOP_UNROLL
 	for (uint32_t i = 0; i != scene.light_count; ++i) {
@@ -728,6 +741,8 @@ PT_FN v3 pt_sample_lights(const PtSceneView& scene, const PtLightCache& cache, f
 		prefix_importance += importance;
 		if (prefix_importance > target_importance) {
 			randoms.x = ((target_importance + importance) - prefix_importance) / importance;
+			if (out_near_distance)
+				*out_near_distance = pt_light_near_distance(light, shading_pos);
 			return pt_sample_spherical_light(light, importance, shading_pos, randoms);
 		}
 	}
@@ -814,7 +829,7 @@ struct PtLightTreeSample {
 // of the density of the returned direction (selection probability times cone
 // density); it is zero and the direction is the zero vector if no light was
 // sampled.
-PT_FN v3 pt_sample_lights_tree(const PtSceneView& scene, float* out_density, PtLightTreeSample* out_sample, v3 shading_pos, v3 normal, v2 randoms) {
+PT_FN v3 pt_sample_lights_tree(const PtSceneView& scene, float* out_density, PtLightTreeSample* out_sample, v3 shading_pos, v3 normal, v2 randoms, float* out_near_distance = NULL) {
 	*out_density = 0.0f;
 	out_sample->leaf = 0;
 	out_sample->probability = 0.0f;
@@ -850,6 +865,8 @@ PT_FN v3 pt_sample_lights_tree(const PtSceneView& scene, float* out_density, PtL
 	if (!(importance > 0.0f))
 		return mk3(0.0f, 0.0f, 0.0f);
 	*out_density = probability / ((2.0f * PT_PI) * importance);
+	if (out_near_distance)
+		*out_near_distance = pt_light_near_distance(light, shading_pos);
 	return pt_sample_spherical_light(light, importance, shading_pos, randoms);
 }
 
@@ -1206,6 +1223,7 @@ struct PtVertexResult {
 	v3 shadow_dir;
 	v3 shadow_weight; // throughput * brdf
 	float shadow_factor; // lambert / (light density + brdf density)
+	float shadow_near;   // where along the shadow ray the sampled light begins (pt_light_near_distance())
 	float next_cone;  // the cone of the extension ray, packed by pt_pack_cone()
 };
 
@@ -1223,6 +1241,7 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 	r.shadow = false;
 	r.next_origin = r.next_dir = r.shadow_dir = r.shadow_weight = mk3(0.0f, 0.0f, 0.0f);
 	r.shadow_factor = 0.0f;
+	r.shadow_near = 0.0f;
 	r.next_cone = 0.0f;
 	// In the NEE estimator emission is weighted by nee_throughput, in the
 	// others by throughput (pathtrace.frag.glsl:231,265,293,323)
@@ -1279,8 +1298,8 @@ PT_FN PtVertexResult pt_shade_vertex(const PtSceneView& scene, const PtConstants
 		tree_sample.leaf = 0;
 		tree_sample.probability = 0.0f;
 		v3 light_dir = light_tree
-			? pt_sample_lights_tree(scene, &sampled_light_density, &tree_sample, s.pos, s.normal, pt_random(sx, sy))
-			: pt_sample_lights(scene, light_cache, &total_light_importance, s.pos, s.normal, pt_random(sx, sy), strategy == PT_STRATEGY_NEE_FAST);
+			? pt_sample_lights_tree(scene, &sampled_light_density, &tree_sample, s.pos, s.normal, pt_random(sx, sy), &r.shadow_near)
+			: pt_sample_lights(scene, light_cache, &total_light_importance, s.pos, s.normal, pt_random(sx, sy), strategy == PT_STRATEGY_NEE_FAST, &r.shadow_near);
 		float lambert_in_0 = dot(s.normal, light_dir);
 		r.next_dir = pt_sample_frostbite_brdf(s, pt_random(sx, sy));
 		float lambert_in_1 = dot(s.normal, r.next_dir);

@@ -226,8 +226,10 @@ __global__ void __launch_bounds__(PT_SHADE_BLOCK, PT_SHADE_WAVES) k_shade(PtShad
 	}
 	if (r.shadow) {
 		pt_store_streaming(&a.wf.sh_o[shadow_slot], mk4(r.next_origin.x, r.next_origin.y, r.next_origin.z, pt_as_float(path)));
-		pt_store_streaming(&a.wf.sh_d[shadow_slot], mk4(r.shadow_dir.x, r.shadow_dir.y, r.shadow_dir.z, r.shadow_factor));
-		pt_store_streaming(&a.wf.sh_w[shadow_slot], mk4(r.shadow_weight.x, r.shadow_weight.y, r.shadow_weight.z, 0.0f));
+		// The direction's fourth word stays in a register of the traversal for the life of the ray: the distance at
+		// which the sampled light begins, which tells it a hit in front of that light from one behind it
+		pt_store_streaming(&a.wf.sh_d[shadow_slot], mk4(r.shadow_dir.x, r.shadow_dir.y, r.shadow_dir.z, r.shadow_near));
+		pt_store_streaming(&a.wf.sh_w[shadow_slot], mk4(r.shadow_weight.x, r.shadow_weight.y, r.shadow_weight.z, r.shadow_factor));
 	}
 }
 

@@ -227,7 +227,12 @@ __device__ __forceinline__ uint32_t pt_lane() { return __builtin_amdgcn_mbcnt_hi
 // With 48 % of the shadow rays blocked (generated city) that saves 17 % of the
 // node visits and 12 % of the time; with 12 to 17 % blocked (Cornell box,
 // generated interior) it costs 7 to 10 %.
-template <bool COUNT_VISITS, bool EMISSIVE_ONLY, typename Finish>
+// AIMED: the fourth word of a ray's direction says how far away the light
+// begins that the ray was aimed at. A hit beyond that distance does not start
+// the skipping: the lamp is likely to turn up in front of it, and every ray
+// that finds its lamp after something was skipped pays with a second walk
+// (9 % of all node steps of the city's shadow rays were second walks, 4 % are).
+template <bool COUNT_VISITS, bool EMISSIVE_ONLY, bool AIMED = false, typename Finish>
 __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache, const PtCacheLayout layout, const PtNode* __restrict__ nodes, const PtTri* __restrict__ tris, uint32_t triangle_count,
 	const PtRayQueue& queue, u32x2* stack_overflow, uint32_t stack_overflow_stride, uint32_t stack_capacity,
 	unsigned long long* visit_counters, uint32_t* error_word, Finish finish, unsigned long long* emissive_counts = NULL)
@@ -608,7 +613,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					tgroup.y = 0;
 					fetched = false;
 				}
-				else
+				else if (!AIMED || hit.t < direction_w)
 					emissive_state |= 1u;
 			}
 		}
@@ -659,7 +664,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					ngroup.y = 0;
 					tgroup.y = 0;
 				}
-				else
+				else if (!AIMED || hit.t < direction_w)
 					emissive_state |= 1u;
 			}
 		}

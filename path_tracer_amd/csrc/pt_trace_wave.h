@@ -231,7 +231,8 @@ __device__ __forceinline__ uint32_t pt_lane() { return __builtin_amdgcn_mbcnt_hi
 // begins that the ray was aimed at. A hit beyond that distance does not start
 // the skipping: the lamp is likely to turn up in front of it, and every ray
 // that finds its lamp after something was skipped pays with a second walk
-// (9 % of all node steps of the city's shadow rays were second walks, 4 % are).
+// (9 % of all node steps of the city's shadow rays were second walks; with
+// this rule hardly any are left).
 template <bool COUNT_VISITS, bool EMISSIVE_ONLY, bool AIMED = false, typename Finish>
 __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache, const PtCacheLayout layout, const PtNode* __restrict__ nodes, const PtTri* __restrict__ tris, uint32_t triangle_count,
 	const PtRayQueue& queue, u32x2* stack_overflow, uint32_t stack_overflow_stride, uint32_t stack_capacity,

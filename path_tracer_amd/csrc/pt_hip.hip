@@ -38,7 +38,7 @@
 
 static_assert(sizeof(pt_constants_t) == sizeof(PtConstants), "ABI and device constants must agree");
 
-#define PT_EMISSIVE_COUNTS_OFFSET 56 // two 64-bit counts of k_trace_shadow<..., true> among the queue counters (words 56 to 59)
+#define PT_EMISSIVE_COUNTS_OFFSET 50 // three 64-bit counts of k_trace_shadow<..., true> among the queue counters (words 50 to 55), then those of k_trace_extension<..., true> (56 to 61)
 
 #define PT_CHECK(call) do { hipError_t pt_err_ = (call); if (pt_err_ != hipSuccess) { \
 	printf("HIP error %s at %s:%d (%s).\n", hipGetErrorString(pt_err_), __FILE__, __LINE__, #call); return 1; } } while (0)
@@ -226,7 +226,8 @@ struct PtTraceArgs {
 	PtCacheLayout cache_layout;
 	unsigned long long* visit_counters; // nodes, triangles of extension rays [0], [1] and of shadow rays [2], [3], or NULL
 	uint32_t* error_word; // PT_ERROR_* bits, checked by pt_synchronize()
-	unsigned long long* emissive_counts; // shadow rays traced and shadow rays that ended at a hit that is not emissive (k_trace_shadow<..., true>)
+	unsigned long long* emissive_counts; // shadow rays traced, shadow rays that ended at a hit that is not emissive, second walks (k_trace_shadow<..., true>)
+	uint32_t aimed; // shadow rays start skipping only at hits in front of the light they were aimed at
 };
 
 // pathtrace.frag.glsl:365-386 for every path of the batch
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(PT_TRACE_BLOCK, PT_WAVES_PER_BLOCK * PT_TRACE_
 				v3 sum = mk3(radiance.x, radiance.y, radiance.z) + term;
 				a.wf.radiance[path] = mk4(sum.x, sum.y, sum.z, 0.0f);
 			}
-		}, a.emissive_counts);
+		}, a.emissive_counts, a.aimed != 0u);
 }
 
 // The marks that shadow rays read (pt_trace_wave<..., EMISSIVE_ONLY = true>): a
@@ -550,6 +551,10 @@ struct pt_scene {
 	// camera of the last pt_render_samples() call: another view has another
 	// share of blocked shadow rays, so the decision is taken anew for it
 	unsigned long long skipping_decided_on_rays, skipping_decided_on_blocked;
+	// Whether skipping shadow rays wait for a hit in front of the light they were aimed at (pt_trace_wave<..., AIMED>):
+	// 0 undecided (they do not, and their second walks are counted), 1 yes, 2 no; fixed by PT_SHADOW_AIMED=0/1
+	int shadow_aimed;
+	bool shadow_aimed_fixed;
 	float skipping_camera[20];
 	// render targets and wavefront buffers
 	uint32_t width, height;
@@ -700,9 +705,18 @@ static void pt_collect(pt_scene* s) {
 		}
 		// The first batch that says enough about the shadow rays of this scene
 		// decides whether they go on skipping: yes if a quarter of them are blocked
-		unsigned long long traced = 0, blocked = 0;
+		unsigned long long traced = 0, blocked = 0, second_walks = 0;
 		memcpy(&traced, &c[PT_EMISSIVE_COUNTS_OFFSET], sizeof(traced));
 		memcpy(&blocked, &c[PT_EMISSIVE_COUNTS_OFFSET + 2], sizeof(blocked));
+		memcpy(&second_walks, &c[PT_EMISSIVE_COUNTS_OFFSET + 4], sizeof(second_walks));
+		// The same batch says whether the lamps that rays are aimed at tend to turn up after something was skipped
+		// (one ray in thirty-two walking twice): then a hit behind the lamp had better not start the skipping
+		if (s->shadow_aimed == 0 && s->pending_counter_reads[i].emissive_marks_serial == s->emissive_marks_serial && traced >= 4096) {
+			s->shadow_aimed = (32 * second_walks >= traced) ? 1 : 2;
+			if (getenv("PT_TRACE_DIAGNOSTICS"))
+				printf("trace diagnostics (shadow): %.1f%% of %llu rays walked twice; a hit behind the light a ray was aimed at %s\n",
+					100.0 * (double) second_walks / (double) traced, traced, (s->shadow_aimed == 1) ? "no longer starts the skipping" : "goes on starting the skipping");
+		}
 		if (s->emissive_skipping == 0 && s->pending_counter_reads[i].emissive_marks_serial == s->emissive_marks_serial && traced >= 4096) {
 			s->emissive_skipping = (4 * blocked >= traced) ? 1 : 2;
 			s->skipping_decided_on_rays = traced;
@@ -1027,6 +1041,9 @@ static int pt_create_scene_impl(pt_scene_t** out_scene, int device_index, const 
 	s->emissive_skipping_fixed = skipping && (skipping[0] == '0' || skipping[0] == '1');
 	s->emissive_skipping = s->emissive_skipping_fixed ? ((skipping[0] == '1') ? 1 : 2) : 0;
 	s->emissive_skipping_last_vertex = !(s->emissive_skipping_fixed && skipping[0] == '0');
+	const char* aimed = getenv("PT_SHADOW_AIMED");
+	s->shadow_aimed_fixed = aimed && (aimed[0] == '0' || aimed[0] == '1');
+	s->shadow_aimed = s->shadow_aimed_fixed ? ((aimed[0] == '1') ? 1 : 2) : 0;
 	s->width = s->height = 0;
 	memset(&s->frame_layout, 0, sizeof(s->frame_layout));
 	s->max_frames_per_batch = 0;
@@ -1331,6 +1348,7 @@ static PtTraceArgs pt_trace_args(pt_scene* s, uint32_t bounce, uint32_t parity, 
 	a.visit_counters = s->visit_counters_enabled ? s->visit_counters : NULL;
 	a.error_word = s->error_word;
 	a.emissive_counts = (unsigned long long*) (s->counters + PT_EMISSIVE_COUNTS_OFFSET);
+	a.aimed = (s->shadow_aimed == 1) ? 1u : 0u;
 	return a;
 }
 
@@ -1344,7 +1362,7 @@ static void pt_launch_trace_extension(pt_scene* s, uint32_t bounce, uint32_t par
 	// their own and decide nothing
 	const bool emissive_only = bounce + 1 == s->path_length && s->emissive_marks_valid && s->emissive_skipping_last_vertex
 		&& a.cache_layout.node_count < s->bvh_info.node_count;
-	a.emissive_counts = (unsigned long long*) (s->counters + PT_EMISSIVE_COUNTS_OFFSET + 4);
+	a.emissive_counts = (unsigned long long*) (s->counters + PT_EMISSIVE_COUNTS_OFFSET + 6);
 	if (s->visit_counters_enabled && emissive_only)
 		hipLaunchKernelGGL((k_trace_extension<true, true>), dim3(pt_trace_grid(s, capacity)), dim3(PT_TRACE_BLOCK), 0, s->stream, a);
 	else if (s->visit_counters_enabled)
@@ -1379,6 +1397,8 @@ static int pt_render_batch(pt_scene* s, uint32_t first_frame_index, uint32_t fra
 				s->nodes, s->bvh_info.node_count, s->tris, level != 0);
 		if (!s->emissive_skipping_fixed)
 			s->emissive_skipping = 0;
+		if (!s->shadow_aimed_fixed)
+			s->shadow_aimed = 0;
 		s->emissive_marks_valid = true;
 		s->emissive_marks_index = s->emission_material_index;
 		++s->emissive_marks_serial;
@@ -1505,8 +1525,11 @@ static int pt_render_samples_impl(pt_scene_t* s, const pt_constants_t* constants
 	camera[19] = (float) constants->camera_type;
 	if (memcmp(camera, s->skipping_camera, sizeof(camera)) != 0) {
 		memcpy(s->skipping_camera, camera, sizeof(camera));
-		if (!s->emissive_skipping_fixed && s->emissive_skipping != 0) {
-			s->emissive_skipping = 0;
+		if ((!s->emissive_skipping_fixed && s->emissive_skipping != 0) || (!s->shadow_aimed_fixed && s->shadow_aimed != 0)) {
+			if (!s->emissive_skipping_fixed)
+				s->emissive_skipping = 0;
+			if (!s->shadow_aimed_fixed)
+				s->shadow_aimed = 0;
 			++s->emissive_marks_serial; // batches queued for the old view decide nothing
 		}
 	}

@@ -227,22 +227,25 @@ __device__ __forceinline__ uint32_t pt_lane() { return __builtin_amdgcn_mbcnt_hi
 // With 48 % of the shadow rays blocked (generated city) that saves 17 % of the
 // node visits and 12 % of the time; with 12 to 17 % blocked (Cornell box,
 // generated interior) it costs 7 to 10 %.
-// AIMED: the fourth word of a ray's direction says how far away the light
+// AIMED (and the argument aimed): the fourth word of a ray's direction says how far away the light
 // begins that the ray was aimed at. A hit beyond that distance does not start
 // the skipping: the lamp is likely to turn up in front of it, and every ray
 // that finds its lamp after something was skipped pays with a second walk
 // (9 % of all node steps of the city's shadow rays were second walks; with
-// this rule hardly any are left).
+// this rule hardly any are left). Where the lights have no emissive geometry
+// to find, the rule only delays the skipping (100 M-triangle city with 10 000
+// generated lights: +30 % time), so emissive_counts[2] counts the second walks
+// and the host turns the rule on where they are frequent.
 template <bool COUNT_VISITS, bool EMISSIVE_ONLY, bool AIMED = false, typename Finish>
 __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache, const PtCacheLayout layout, const PtNode* __restrict__ nodes, const PtTri* __restrict__ tris, uint32_t triangle_count,
 	const PtRayQueue& queue, u32x2* stack_overflow, uint32_t stack_overflow_stride, uint32_t stack_capacity,
-	unsigned long long* visit_counters, uint32_t* error_word, Finish finish, unsigned long long* emissive_counts = NULL)
+	unsigned long long* visit_counters, uint32_t* error_word, Finish finish, unsigned long long* emissive_counts = NULL, bool aimed = false)
 {
 	// EMISSIVE_ONLY: rays traced, and rays that ended at a hit that is not
 	// emissive, are added to emissive_counts[0] and [1]: the host leaves the
 	// skipping off for scenes in which few rays end so (lights mostly in view:
 	// little to skip, and keeping track of it costs more than it saves)
-	uint32_t finished_count = 0, blocked_count = 0;
+	uint32_t finished_count = 0, blocked_count = 0, second_walk_count = 0;
 	const uint32_t lane = pt_lane();
 	const uint32_t ray_total = *queue.count;
 	// Eighths of the queue, in multiples of the reservation size
@@ -614,7 +617,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					tgroup.y = 0;
 					fetched = false;
 				}
-				else if (!AIMED || hit.t < direction_w)
+				else if (!(AIMED && aimed) || hit.t < direction_w)
 					emissive_state |= 1u;
 			}
 		}
@@ -665,15 +668,19 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 					ngroup.y = 0;
 					tgroup.y = 0;
 				}
-				else if (!AIMED || hit.t < direction_w)
+				else if (!(AIMED && aimed) || hit.t < direction_w)
 					emissive_state |= 1u;
 			}
 		}
 
 #endif
 		// ---- retire complete rays ----
-		if (active && !fetched && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0) {
-			if (EMISSIVE_ONLY && emissive_state == 2u) {
+		const bool complete = active && !fetched && !(ngroup.y & 0xff000000u) && sp == 0 && (tgroup.y & 0xffu) == 0;
+		const bool walks_again = EMISSIVE_ONLY && complete && emissive_state == 2u;
+		if (EMISSIVE_ONLY)
+			second_walk_count += (uint32_t) __popcll(__ballot(walks_again));
+		if (complete) {
+			if (walks_again) {
 				// Emissive, but not everything in front of it has been looked at
 				emissive_state = 4u;
 				ngroup.x = 0;
@@ -691,6 +698,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 	if (EMISSIVE_ONLY && lane == 0) {
 		atomicAdd(&emissive_counts[0], (unsigned long long) finished_count);
 		atomicAdd(&emissive_counts[1], (unsigned long long) blocked_count);
+		atomicAdd(&emissive_counts[2], (unsigned long long) second_walk_count);
 	}
 	if (COUNT_VISITS) {
 		atomicAdd(&visit_counters[0], (unsigned long long) node_visits);

@@ -1638,7 +1638,7 @@ static int pt_get_statistics_impl(pt_scene_t* s, pt_statistics_t* out) {
 			printf("trace diagnostics (%s): the lanes of a pass with a node step fetch %.1f different nodes on average (%.1f lanes take part)\n", k ? "shadow" : "extension",
 				(double) visits[24 + 2 * k] / (double) (visits[16 + 2 * k] ? visits[16 + 2 * k] : 1), (double) visits[2 * k] / (double) (visits[16 + 2 * k] ? visits[16 + 2 * k] : 1));
 			printf("trace diagnostics (%s): wave passes %llu, lanes holding a ray %.1f%%, refills %llu, passes with a node step %llu (%.1f%% of lanes in them), with a triangle test %llu (%.1f%%)\n",
-				k ? "shadow" : "extension", visits[6 + 2 * k], 100.0 * (double) visits[7 + 2 * k] / (64.0 * (double) visits[6 + 2 * k]), visits[10 + 2 * k],
+				k ? "shadow" : "extension", visits[6 + 2 * k], 100.0 * (double) visits[7 + 2 * k] / (64.0 * (double) visits[6 + 2 * k]), visits[25 + 2 * k],
 				visits[16 + 2 * k], 100.0 * (double) visits[2 * k] / (64.0 * (double) visits[16 + 2 * k]), visits[17 + 2 * k], 100.0 * (double) visits[1 + 2 * k] / (64.0 * (double) visits[17 + 2 * k]));
 		}
 	s->stats.shadow_skipping = (uint32_t) s->emissive_skipping;

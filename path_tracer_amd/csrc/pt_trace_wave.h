@@ -713,7 +713,7 @@ __device__ __forceinline__ void pt_trace_wave(PtWaveLds& lds, const u32x4* cache
 			// Diagnostics: passes, lanes active in them, refills (summed over waves)
 			atomicAdd(&visit_counters[6], (unsigned long long) pass_count);
 			atomicAdd(&visit_counters[7], active_lane_passes);
-			atomicAdd(&visit_counters[10], (unsigned long long) refill_count);
+			atomicAdd(&visit_counters[25], (unsigned long long) refill_count); // not [10]: the shadow rays' counters start two words on, and [12] is taken
 			atomicAdd(&visit_counters[16], (unsigned long long) node_pass_count);
 			atomicAdd(&visit_counters[17], (unsigned long long) tri_pass_count);
 			atomicAdd(&visit_counters[24], (unsigned long long) distinct_node_fetches);

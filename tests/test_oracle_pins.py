@@ -243,3 +243,61 @@ def test_oracle_regression_vectors():
         assert rays == int(expected_rays[name]), name
         assert (image.view(np.uint32) == expected.view(np.uint32)).all(), name
         assert image[..., :3].max() > 0
+
+
+@pytest.mark.parametrize("tracer", ["oracle", "kernel bodies"])
+def test_ray_queries_against_double_precision(tracer):
+    """What a ray query returns (pathtrace.frag.glsl:184-197 leaves it to Vulkan): the closest intersection with
+    t > 1e-3, barycentric coordinates of the second and third vertex, front face where the triangle appears
+    counter-clockwise... as pinned on the Cornell box, i.e. dot(cross(v1 - v0, v2 - v0), direction) < 0. Checked against
+    a ray/triangle intersection in double precision over all triangles (Moeller-Trumbore, numpy), which shares no
+    code with the oracle's watertight test, on the rays whose answer does not hinge on the last bits: the hit is not
+    within 1e-4 of an edge, no other triangle comes within 1e-4 of being hit first."""
+    from tests import emu, synthetic
+    scene = synthetic.triangle_soup(seed=91, triangle_count=400, material_count=2, size=1.2, texture_size=4)
+    words = scene.positions.reshape(-1, 3, 2).astype(np.uint64)
+    quantized = np.stack([words[..., 0] & 0x1fffff, (words[..., 0] >> 21) | ((words[..., 1] & 0x3ff) << 11), (words[..., 1] >> 10) & 0x1fffff], axis=2)
+    vertices = quantized.astype(np.float64) * scene.dequantization_factor.astype(np.float64) + scene.dequantization_summand.astype(np.float64)
+    rng = np.random.default_rng(92)
+    count = 6000
+    origins = rng.uniform(-6.0, 6.0, (count, 3)).astype(np.float32)
+    directions = rng.normal(size=(count, 3))
+    directions = (directions / np.linalg.norm(directions, axis=1, keepdims=True)).astype(np.float32)
+    o, d = origins.astype(np.float64)[:, None, :], directions.astype(np.float64)[:, None, :]
+    v0, e1, e2 = vertices[None, :, 0], (vertices[:, 1] - vertices[:, 0])[None], (vertices[:, 2] - vertices[:, 0])[None]
+    p = np.cross(d, e2)
+    det = (e1 * p).sum(axis=2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = 1.0 / det
+        tv = o - v0
+        u = (tv * p).sum(axis=2) * inv
+        q = np.cross(tv, e1)
+        v = (d * q).sum(axis=2) * inv
+        t = (e2 * q).sum(axis=2) * inv
+    inside = np.minimum(np.minimum(u, v), 1.0 - u - v)
+    margin = 1e-4
+    ahead = np.isfinite(t) & (t > 1e-3 * (1.0 + margin))
+    sure = ahead & (inside > margin)
+    maybe = np.isfinite(t) & (t > 1e-3 * (1.0 - margin)) & (inside > -margin)
+    t_sure = np.where(sure, t, np.inf)
+    best = t_sure.argmin(axis=1)
+    best_t = t_sure.min(axis=1)
+    hit = np.isfinite(best_t)
+    # Nothing doubtful may come first, and no second sure hit may be as near as the first
+    others = np.where(maybe, t, np.inf)
+    others[np.arange(count), np.where(hit, best, 0)] = np.where(hit, np.inf, others[np.arange(count), 0])
+    robust_hit = hit & (others.min(axis=1) > best_t * (1.0 + margin))
+    robust_miss = ~maybe.any(axis=1)
+    assert robust_hit.sum() > 0.25 * count and robust_miss.sum() > 0.05 * count
+    tracer_scene = oracle.OracleScene(scene) if tracer == "oracle" else emu.EmuScene(scene)
+    result = tracer_scene.trace_rays(origins, directions)
+    triangles, tuv, front = result[0], result[1], result[2]
+    assert (triangles[robust_miss] == -1).all()
+    rays = np.flatnonzero(robust_hit)
+    assert (triangles[rays] == best[rays]).all()
+    # Single precision on coordinates of up to eight units: a few 1e-5 in distance, less in the coordinates
+    np.testing.assert_allclose(tuv[rays, 0], best_t[rays], rtol=2e-5, atol=5e-5)
+    np.testing.assert_allclose(tuv[rays, 1], u[rays, best[rays]], atol=1e-4)
+    np.testing.assert_allclose(tuv[rays, 2], v[rays, best[rays]], atol=1e-4)
+    # det = dot(v1 - v0, cross(direction, v2 - v0)) = -dot(cross(v1 - v0, v2 - v0), direction)
+    assert (front[rays].astype(bool) == (det[rays, best[rays]] > 0.0)).all()

@@ -301,3 +301,95 @@ def test_ray_queries_against_double_precision(tracer):
     np.testing.assert_allclose(tuv[rays, 2], v[rays, best[rays]], atol=1e-4)
     # det = dot(v1 - v0, cross(direction, v2 - v0)) = -dot(cross(v1 - v0, v2 - v0), direction)
     assert (front[rays].astype(bool) == (det[rays, best[rays]] > 0.0)).all()
+
+
+@pytest.mark.parametrize("restatement", ["oracle", "kernel bodies"])
+def test_shading_data_against_a_restatement_in_double_precision(restatement):
+    """get_shading_data() (shading_data.glsl:51-103) with dequantize_position() and dequantize_normal()
+    (mesh_quantization.glsl:4-31), written out again in numpy and double precision for random triangles with random
+    vertex normals and texture coordinates, materials of one colour each (so that texture filtering, which has its
+    own tests, does not enter: the decoded texel values are read through the test hook) with tilted normal maps,
+    front and back faces, and directions towards the camera on both sides of the surface: position, shading normal
+    (tangent frame from the texture coordinates, the bend towards the camera), albedo, Fresnel term, roughness and
+    emission agree to single precision."""
+    from tests import emu, synthetic
+    soup = synthetic.triangle_soup(seed=131, triangle_count=300, material_count=4, size=0.8, texture_size=4)
+    values = [((0.0, 0.0, 0.0), (1.0, 1.0, 0.0), (0.5, 0.5)), ((0.8, 0.3, 0.2), (0.3, 0.7, 0.0), (0.5, 0.5)),
+              ((0.2, 0.6, 0.9), (0.9, 0.3, 1.0), (0.8, 0.35)), ((0.5, 0.5, 0.1), (0.5, 0.05, 0.4), (0.2, 0.7))]
+    textures = []
+    for base, specular, normal in values:
+        textures += [synthetic.constant_texture(base, 132), synthetic.constant_texture(specular, 131), synthetic.constant_texture(normal, 141)]
+    scene = formats.Scene(soup.material_names, soup.triangle_count, soup.dequantization_factor, soup.dequantization_summand,
+                          soup.positions, soup.normals_uvs, soup.materials, textures)
+    checker = oracle.OracleScene(scene)
+    subject = checker if restatement == "oracle" else emu.EmuScene(scene)
+    rng = np.random.default_rng(132)
+    count = 2000
+    triangles = rng.integers(0, scene.triangle_count, count)
+    barys = rng.dirichlet((1.0, 1.0, 1.0), count)[:, 1:]
+    front = rng.integers(0, 2, count).astype(np.uint8)
+    out_dirs = rng.normal(size=(count, 3))
+    out_dirs /= np.linalg.norm(out_dirs, axis=1, keepdims=True)
+    spec = synthetic.look_at_spec((0.5, 7.0, 0.3), (1.3, 0.0, 0.4), emission_strength=3.0)
+    constants = oracle.write_constants(spec, 16, 16, scene, np.zeros((0, 4), np.float32))
+    got = subject.shading_data(constants, triangles, barys.astype(np.float32), front, out_dirs.astype(np.float32)).astype(np.float64)
+
+    # ---- the restatement ----
+    barys = barys.astype(np.float32).astype(np.float64)
+    out_dirs = out_dirs.astype(np.float32).astype(np.float64)
+    weights = np.stack([1.0 - barys[:, 0] - barys[:, 1], barys[:, 0], barys[:, 1]], axis=1)
+    words = scene.positions.reshape(-1, 3, 2).astype(np.uint64)[triangles]
+    quantized = np.stack([words[..., 0] & 0x1fffff, (words[..., 0] >> 21) | ((words[..., 1] & 0x3ff) << 11), (words[..., 1] >> 10) & 0x1fffff], axis=2)
+    poss = quantized.astype(np.float64) * scene.dequantization_factor.astype(np.float64) + scene.dequantization_summand.astype(np.float64)
+    attributes = scene.normals_uvs.reshape(-1, 3, 4)[triangles].astype(np.float64) / 65535.0
+    factor = 2.0 * (65534.0 / 65535.0)
+    octahedral = attributes[..., 0:2] * factor - (32768.0 / 65535.0) * factor
+    normals = np.concatenate([octahedral, 1.0 - np.abs(octahedral).sum(axis=2, keepdims=True)], axis=2)
+    folded = (1.0 - np.abs(normals[..., [1, 0]])) * np.where(octahedral >= 0.0, 1.0, -1.0)
+    normals[..., 0:2] = np.where(normals[..., 2:3] < 0.0, folded, normals[..., 0:2])
+    normals /= np.linalg.norm(normals, axis=2, keepdims=True)
+    tex_coords = attributes[..., 2:4] * np.array([8.0, -8.0]) + np.array([0.0, 1.0])
+    pos = (weights[:, :, None] * poss).sum(axis=1)
+    normal_geo = (weights[:, :, None] * normals).sum(axis=1)
+    normal_geo /= np.linalg.norm(normal_geo, axis=1, keepdims=True)
+    material = scene.materials[triangles].astype(np.int64)
+    texel = {m: [checker.sample_texture(3 * m + i, [[0.3, 0.6]])[0].astype(np.float64) for i in range(3)] for m in range(4)}
+    base = np.array([texel[m][0] for m in material])
+    specular = np.array([texel[m][1] for m in material])
+    normal_tex = np.array([texel[m][2][:2] for m in material])
+    local = np.zeros((count, 3))
+    local[:, 0:2] = normal_tex * 2.0 - 1.0
+    local[:, 2] = np.sqrt(np.maximum(0.0, 1.0 - local[:, 0] ** 2 - local[:, 1] ** 2))
+    edge_1, edge_2 = tex_coords[:, 1] - tex_coords[:, 0], tex_coords[:, 2] - tex_coords[:, 0]
+    pre_0 = np.cross(normal_geo, poss[:, 1] - poss[:, 0])
+    pre_1 = np.cross(normal_geo, poss[:, 0] - poss[:, 2])
+    # mat2(a, b)[0] is the column a: tex_edges[0][0] = edge_1.x, tex_edges[1][0] = edge_2.x
+    tangent_0 = pre_1 * edge_1[:, 0:1] + pre_0 * edge_2[:, 0:1]
+    tangent_1 = pre_1 * edge_1[:, 1:2] + pre_0 * edge_2[:, 1:2]
+    mean_length = np.sqrt(0.5 * ((tangent_0 ** 2).sum(axis=1) + (tangent_1 ** 2).sum(axis=1)))
+    local[:, 2] *= np.maximum(1.0e-8, mean_length)
+    normal = tangent_0 * local[:, 0:1] + tangent_1 * local[:, 1:2] + normal_geo * local[:, 2:3]
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    normal = np.where(front[:, None] != 0, normal, -normal)
+    offset = np.maximum(0.0, 1.0e-3 - (normal * out_dirs).sum(axis=1))
+    normal = normal + offset[:, None] * out_dirs
+    normal /= np.linalg.norm(normal, axis=1, keepdims=True)
+    metalicity = specular[:, 2:3]
+    expected = np.zeros((count, 20))
+    expected[:, 0:3] = pos
+    expected[:, 3:6] = normal
+    expected[:, 6:9] = out_dirs
+    expected[:, 9] = (normal * out_dirs).sum(axis=1)
+    expected[:, 10:13] = np.where(material[:, None] == scene.emission_material_index, np.array(constants.emission_material_radiance[:3]), 0.0)
+    expected[:, 13:16] = base - metalicity * base
+    expected[:, 16:19] = 0.02 * (1.0 - metalicity) + base * metalicity
+    expected[:, 19] = np.maximum(0.006, specular[:, 1] ** 2)
+    # Where the tangent frame nearly degenerates (texture coordinates of a triangle nearly collinear) the normal
+    # hinges on the last bits of single precision; everywhere else it agrees to a few 1e-5
+    stable = mean_length > 1e-3
+    assert stable.mean() > 0.95 and (material == scene.emission_material_index).any() and (offset > 0.0).mean() > 0.3
+    np.testing.assert_allclose(got[:, 0:3], expected[:, 0:3], atol=2e-5)
+    np.testing.assert_allclose(got[stable, 3:6], expected[stable, 3:6], atol=2e-4)
+    np.testing.assert_allclose(got[stable, 9], expected[stable, 9], atol=2e-4)
+    np.testing.assert_allclose(got[:, 6:9], expected[:, 6:9], atol=1e-6)
+    np.testing.assert_allclose(got[:, 10:20], expected[:, 10:20], atol=2e-6, rtol=2e-6)

@@ -393,3 +393,44 @@ def test_shading_data_against_a_restatement_in_double_precision(restatement):
     np.testing.assert_allclose(got[stable, 9], expected[stable, 9], atol=2e-4)
     np.testing.assert_allclose(got[:, 6:9], expected[:, 6:9], atol=1e-6)
     np.testing.assert_allclose(got[:, 10:20], expected[:, 10:20], atol=2e-6, rtol=2e-6)
+
+
+def test_camera_rays_against_unprojection_in_double_precision():
+    """The camera ray of a pixel (pathtrace.frag.glsl:368-380, camera_utilities.glsl:9-44: Gaussian jitter of 0.9
+    pixels from the first random pair, origin on the near plane, direction from the minors of the world to
+    projection space matrix) against plain unprojection in double precision: the point where the ray of every pixel
+    meets a floor must be the point where the line through the unprojected near and far points of the jittered pixel
+    position meets it. Pins the pixel to ray mapping (orientation of both axes, pixel centres, the jitter's scale)
+    through the primary hits of the oracle."""
+    from tests import synthetic
+    scene = synthetic.furnace_scene(half_extent=200.0)
+    spec = synthetic.look_at_spec((1.5, -6.0, 4.0), (1.0, 0.0, 0.35), sky_strength=1.0)
+    width, height, frame = 48, 32, 77
+    constants = oracle.write_constants(spec, width, height, scene, np.zeros((0, 4), np.float32))
+    triangles, barys, front = oracle.OracleScene(scene).primary_hits(constants, frame)
+    hit = triangles >= 0
+    assert hit.mean() > 0.3
+    words = scene.positions.reshape(-1, 3, 2).astype(np.uint64)
+    quantized = np.stack([words[..., 0] & 0x1fffff, (words[..., 0] >> 21) | ((words[..., 1] & 0x3ff) << 11), (words[..., 1] >> 10) & 0x1fffff], axis=2)
+    vertices = quantized.astype(np.float64) * scene.dequantization_factor.astype(np.float64) + scene.dequantization_summand.astype(np.float64)
+    projection_to_world = np.linalg.inv(np.array(constants.world_to_projection_space, np.float64).reshape(4, 4))
+    worst = 0.0
+    for y in range(height):
+        for x in range(width):
+            if not hit[y, x]:
+                continue
+            u = oracle.rng_stream(x, y, frame, 1)[0][0].astype(np.float64)
+            jitter = 0.9 * np.sqrt(2.0) * scipy.special.erfinv(2.0 * u - 1.0)
+            ndc = 2.0 * (np.array([x + 0.5, y + 0.5]) + jitter) / np.array([width, height]) - 1.0
+            near = projection_to_world @ np.array([ndc[0], ndc[1], 0.0, 1.0])
+            far = projection_to_world @ np.array([ndc[0], ndc[1], 1.0, 1.0])
+            near, far = near[:3] / near[3], far[:3] / far[3]
+            direction = far - near
+            expected = near - near[2] / direction[2] * direction
+            b = barys[y, x].astype(np.float64)
+            v = vertices[triangles[y, x]]
+            got = (1.0 - b[0] - b[1]) * v[0] + b[0] * v[1] + b[1] * v[2]
+            distance = np.linalg.norm(expected - near)
+            worst = max(worst, np.linalg.norm(got - expected) / distance)
+    # Single precision in the matrix inverse, the minors and the intersection: a few 1e-6 of the distance
+    assert worst < 5e-5, worst

@@ -434,3 +434,50 @@ def test_camera_rays_against_unprojection_in_double_precision():
             worst = max(worst, np.linalg.norm(got - expected) / distance)
     # Single precision in the matrix inverse, the minors and the intersection: a few 1e-6 of the distance
     assert worst < 5e-5, worst
+
+
+@pytest.mark.parametrize("camera_type", [2, 3])
+def test_hemispherical_and_spherical_camera_rays(camera_type):
+    """The rays of the hemispherical and the spherical camera (pathtrace.frag.glsl:381-386 with
+    sample_hemisphere_spherical() at :48-53 and the frame of brdfs.glsl:126-134, which is the published branchless
+    frame of Duff et al.), written out again in double precision: the direction from the camera position to the point
+    where a pixel's ray meets a floor is the frame about the camera's normal applied to the spherical coordinates of
+    the jittered pixel position."""
+    from tests import synthetic
+    scene = synthetic.furnace_scene(half_extent=500.0)
+    spec = synthetic.look_at_spec((0.3, -0.2, 3.0), (np.pi - 0.4, 0.0, 0.3), sky_strength=1.0, camera_type=camera_type)
+    width, height, frame = 40, 24, 5
+    constants = oracle.write_constants(spec, width, height, scene, np.zeros((0, 4), np.float32))
+    normal = np.array(constants.hemispherical_camera_normal[:3], np.float64)
+    position = np.array(constants.camera_pos[:3], np.float64)
+    assert normal[2] < -0.5 and abs(np.linalg.norm(normal) - 1.0) < 1e-6
+    sign = np.copysign(1.0, normal[2])
+    a = -1.0 / (sign + normal[2])
+    b = normal[0] * normal[1] * a
+    tangent_0 = np.array([1.0 + sign * normal[0] * normal[0] * a, sign * b, -sign * normal[0]])
+    tangent_1 = np.array([b, sign + normal[1] * normal[1] * a, -normal[1]])
+    triangles, barys, front = oracle.OracleScene(scene).primary_hits(constants, frame)
+    hit = triangles >= 0
+    assert hit.mean() > (0.5 if camera_type == 2 else 0.25)
+    words = scene.positions.reshape(-1, 3, 2).astype(np.uint64)
+    quantized = np.stack([words[..., 0] & 0x1fffff, (words[..., 0] >> 21) | ((words[..., 1] & 0x3ff) << 11), (words[..., 1] >> 10) & 0x1fffff], axis=2)
+    vertices = quantized.astype(np.float64) * scene.dequantization_factor.astype(np.float64) + scene.dequantization_summand.astype(np.float64)
+    worst = 0.0
+    for y in range(height):
+        for x in range(width):
+            if not hit[y, x]:
+                continue
+            u = oracle.rng_stream(x, y, frame, 1)[0][0].astype(np.float64)
+            jittered = np.array([x + 0.5, y + 0.5]) + 0.9 * np.sqrt(2.0) * scipy.special.erfinv(2.0 * u - 1.0)
+            coordinates = jittered * np.array([1.0, 2.0 if camera_type == 3 else 1.0]) / np.array([width, height])
+            azimuth, inclination = 2.0 * np.pi * coordinates[0] - np.pi, 0.5 * np.pi * coordinates[1]
+            local = np.array([np.sin(inclination) * np.cos(azimuth), np.sin(inclination) * np.sin(azimuth), np.cos(inclination)])
+            expected = tangent_0 * local[0] + tangent_1 * local[1] + normal * local[2]
+            weights = barys[y, x].astype(np.float64)
+            v = vertices[triangles[y, x]]
+            got = (1.0 - weights[0] - weights[1]) * v[0] + weights[0] * v[1] + weights[1] * v[2] - position
+            got /= np.linalg.norm(got)
+            if expected[2] > -0.02:
+                continue  # grazing the floor: the meeting point is too far away to tell directions apart
+            worst = max(worst, np.linalg.norm(got - expected))
+    assert worst < 5e-5, worst

@@ -17,7 +17,11 @@
  * restatement: every density integrates to one, every sampler follows its
  * density, a surface under a uniform sky reflects the directional albedo that
  * a double-precision numpy restatement of frostbite_brdf() gives, and the four
- * estimators agree (tests/test_estimator_pins.py). Ray/triangle intersection
+ * estimators agree (tests/test_estimator_pins.py), (e) restatements in numpy
+ * and double precision that share no code with this file: ray queries against
+ * an intersection test over all triangles, get_shading_data() with both
+ * dequantisations, the rays of all four cameras against unprojection and
+ * spherical coordinates (tests/test_oracle_pins.py). Ray/triangle intersection
  * and texture filtering happen inside the Vulkan driver in the reference and
  * are "parity unpinned": the oracle defines them (watertight ray/triangle
  * test, float trilinear filtering of hand-decoded BC1/BC5 blocks at a level

@@ -8,15 +8,19 @@
 #include <stdlib.h>
 #include <string.h>
 
-static char* cat_strings(const char* const* parts, uint32_t part_count) {
-	size_t length = 0;
-	for (uint32_t i = 0; i != part_count; ++i)
-		length += strlen(parts[i]);
-	char* result = malloc(length + 1);
-	result[0] = 0;
-	for (uint32_t i = 0; i != part_count; ++i)
-		strcat(result, parts[i]);
-	return result;
+/* Where the texture of one kind of a material is looked for: <directory>/<material><suffix>, with the suffixes of
+   src/scene.c:380-383. The caller frees the string. */
+static char* texture_file_path(const char* directory, const char* material_name, material_texture_type_t type) {
+	static const char* const suffixes[material_texture_type_count] = {
+		[material_texture_type_base_color] = "_BaseColor.vkt",
+		[material_texture_type_specular] = "_Specular.vkt",
+		[material_texture_type_normal] = "_Normal.vkt",
+	};
+	size_t size = strlen(directory) + 1 + strlen(material_name) + strlen(suffixes[type]) + 1;
+	char* path = malloc(size);
+	if (path)
+		snprintf(path, size, "%s/%s%s", directory, material_name, suffixes[type]);
+	return path;
 }
 
 static int load_scene_on(scene_t* scene, const int* device_indices, uint32_t device_count, bool use_context, const char* file_path, const char* texture_path);
@@ -110,15 +114,14 @@ static int load_scene_on(scene_t* scene, const int* device_indices, uint32_t dev
 		/* src/scene.c:377-399: three textures per material */
 		texture_count = header->material_count * material_texture_type_count;
 		texture_file_paths = calloc(texture_count ? texture_count : 1, sizeof(char*));
-		const char* suffixes[material_texture_type_count];
-		suffixes[material_texture_type_base_color] = "_BaseColor.vkt";
-		suffixes[material_texture_type_specular] = "_Specular.vkt";
-		suffixes[material_texture_type_normal] = "_Normal.vkt";
-		for (uint64_t i = 0; i != header->material_count; ++i) {
-			for (uint32_t j = 0; j != material_texture_type_count; ++j) {
-				const char* parts[] = { texture_path, "/", header->material_names[i], suffixes[j] };
-				texture_file_paths[i * material_texture_type_count + j] = cat_strings(parts, 4);
-			}
+		bool paths_complete = texture_file_paths != NULL;
+		for (uint64_t k = 0; paths_complete && k != texture_count; ++k) {
+			texture_file_paths[k] = texture_file_path(texture_path, header->material_names[k / material_texture_type_count], (material_texture_type_t) (k % material_texture_type_count));
+			paths_complete = texture_file_paths[k] != NULL;
+		}
+		if (!paths_complete) {
+			printf("Out of memory for the texture file names of the scene file at %s.\n", file_path);
+			break;
 		}
 		if (load_textures(&textures, (const char* const*) texture_file_paths, (uint32_t) texture_count)) {
 			printf("Failed to load textures for the scene file at %s.\n", file_path);
